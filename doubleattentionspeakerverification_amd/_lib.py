@@ -1,0 +1,75 @@
+"""ctypes binding of libdasv_hip.so (include/dasv_hip.h).
+
+There is no fallback: if the library is missing or a symbol cannot be bound,
+importing the compute path raises.  Build it with
+``python -m doubleattentionspeakerverification_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+import threading
+
+from . import build as _build
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_int64, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+_FWD_ARGS = [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]
+
+# name -> (restype, argtypes); must list every function include/dasv_hip.h declares
+SIGNATURES = {
+    "dasv_abi_version": (c_int, []),
+    "dasv_error_string": (ctypes.c_char_p, [c_int]),
+    "dasv_dmha_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dasv_dmha_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "dasv_dmha_fwd": (c_int, [c_int] + _FWD_ARGS),
+    "dasv_dmha_fwd_f32": (c_int, _FWD_ARGS),
+    "dasv_dmha_fwd_bf16": (c_int, _FWD_ARGS),
+    "dasv_dmha_fwd_f16": (c_int, _FWD_ARGS),
+    "dasv_dmha_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dasv_dmha_bwd": (c_int, [c_int] + [c_void_p] * 13 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int]),
+    "dasv_debug_last_variant": (ctypes.c_char_p, []),
+}
+
+DTYPE_CODES = {"float32": 0, "bfloat16": 1, "float16": 2}
+
+
+class DasvError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.lib_path()
+
+
+def load():
+    """Load (once) and return the bound library.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise DasvError(
+                "HIP library %s is not built; run `python -m doubleattentionspeakerverification_amd.build`. "
+                "There is no CPU fallback for this path." % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dasv_abi_version() != 1:
+            raise DasvError("libdasv_hip.so ABI version %d, expected 1" % lib.dasv_abi_version())
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().dasv_error_string(code)
+        raise DasvError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))

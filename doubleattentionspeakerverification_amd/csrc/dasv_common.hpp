@@ -1,0 +1,109 @@
+// Shared device helpers for the gfx950 DoubleMHA kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dasv {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---- element types of the frame embeddings -------------------------------
+struct F32 { using storage = float; static constexpr int kCode = 0; };
+struct BF16 { using storage = uint16_t; static constexpr int kCode = 1; };
+struct F16 { using storage = uint16_t; static constexpr int kCode = 2; };
+
+template <typename XT> struct Elem;
+template <> struct Elem<F32> {
+    static constexpr int kBytes = 4;
+    static constexpr int kPerVec = 4;  // elements in one 16-byte vector
+    __device__ static __forceinline__ float load1(const void* p, long long i) { return static_cast<const float*>(p)[i]; }
+    __device__ static __forceinline__ void store1(void* p, long long i, float v) { static_cast<float*>(p)[i] = v; }
+    __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Elem<BF16> {
+    static constexpr int kBytes = 2;
+    static constexpr int kPerVec = 8;
+    __device__ static __forceinline__ float cvt(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+    __device__ static __forceinline__ uint32_t rnd(float f) {  // round-to-nearest-even, NaN stays NaN
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    __device__ static __forceinline__ float load1(const void* p, long long i) { return cvt(static_cast<const uint16_t*>(p)[i]); }
+    __device__ static __forceinline__ void store1(void* p, long long i, float v) { static_cast<uint16_t*>(p)[i] = (uint16_t)rnd(v); }
+    __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(w[k] << 16); f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = rnd(f[2 * k]) | (rnd(f[2 * k + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Elem<F16> {
+    static constexpr int kBytes = 2;
+    static constexpr int kPerVec = 8;
+    __device__ static __forceinline__ float cvt(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    __device__ static __forceinline__ uint16_t rnd(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    __device__ static __forceinline__ float load1(const void* p, long long i) { return cvt(static_cast<const uint16_t*>(p)[i]); }
+    __device__ static __forceinline__ void store1(void* p, long long i, float v) { static_cast<uint16_t*>(p)[i] = rnd(v); }
+    __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] = cvt((uint16_t)(w[k] & 0xffffu)); f[2 * k + 1] = cvt((uint16_t)(w[k] >> 16)); }
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)rnd(f[2 * k]) | ((uint32_t)rnd(f[2 * k + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---- cross-lane reductions (all lanes of the wave must be active) --------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over aligned groups of G lanes (G a power of two <= 64); every lane gets its group's sum.
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+template <int G> __device__ __forceinline__ float group_max(float v) {
+    if constexpr (G >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if constexpr (G >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if constexpr (G >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if constexpr (G >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    if constexpr (G >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if constexpr (G >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+
+// write-through (agent-scope) accesses for data exchanged between workgroups inside one launch
+__device__ __forceinline__ void store_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__host__ __device__ inline int round_up_i(int a, int m) { return (a + m - 1) / m * m; }
+
+}  // namespace dasv

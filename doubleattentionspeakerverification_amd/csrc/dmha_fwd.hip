@@ -1,0 +1,526 @@
+// Fused double multi-head attention pooling, forward, for gfx950 (MI355X).
+//
+// Replaces the eager op chain of the reference's scripts/poolings.py
+//   :73-80  innerKeyValueAttention  (matmul -> diagonal -> softmax over T -> broadcast mul -> sum)
+//   :45-51, :61-71 HeadAttention    (matvec -> [mask] -> softmax over H -> weighted sum)
+//   :126-129 DoubleMHA.forward
+// with one launch that streams x[B,T,D] from HBM exactly once.
+//
+// Work decomposition (HBM-bound: ~1 FLOP/byte, so no MFMA; the job is to keep
+// enough 16-byte loads in flight on all 256 CUs):
+//   unit      = one (utterance b, head h): T rows of dh contiguous elements.
+//   group     = G lanes that own one row of a unit at a time; a lane loads NI
+//               16-byte vectors per row (vector c + G*j of the row), so one
+//               wave-instruction fetches 64/G whole G*16-byte row segments.
+//   score     = per-lane partial dot with the (pre-scaled) query fragment,
+//               summed over the group with DPP row operations.
+//   softmax   = per-group online (max, sum, weighted accumulator) in registers;
+//               groups of a wave are merged by xor-shuffles, waves of a unit
+//               through LDS.  Raw scores are parked in LDS so the normalised
+//               alignments are written once, after the unit's (max, sum) is known.
+//   head stage= per-head context vectors go to ctx[B,H,dh] with write-through
+//               (agent scope) stores; a per-utterance arrival counter elects the
+//               last workgroup of each utterance, which re-reads the H vectors
+//               with agent-scope loads and finishes softmax-over-heads + output.
+//               Workgroups of one utterance share blockIdx % 8 (one XCD's L2 under
+//               round-robin placement): speed only, correctness never depends on it.
+#include "dasv_common.hpp"
+#include "../../include/dasv_hip.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace dasv {
+
+struct FwdParams {
+    const void* x;
+    const float* query;    // [dh,H]
+    const float* att;      // [dh] or null
+    const uint8_t* keep;   // [B,H] or null
+    const int32_t* lengths;  // [B] or null
+    float* out;            // [B,dh]
+    float* align;          // [B,T,H] or null
+    float* head_w;         // [B,H] or null
+    float* ctx;            // [B,H,dh]
+    float* ml;             // [B,H,2] or null
+    int* counters;         // [B] arrival counters (zero between launches)
+    long long sb, st;      // element strides of x
+    int B, T, H, dh;
+    int wpu;               // waves cooperating on one unit
+    int upw;               // units per workgroup
+    int arrivals;          // workgroups per utterance = H / upw
+    int t_pad;             // LDS score row pitch (floats)
+    float qscale;          // log2(e) / sqrt(H)
+};
+
+// LDS carve (floats): [upw][t_pad] scores | [NW][2] (m,l) | [NW][dh] acc | [H][dh] ctx copy | [H] u | flag
+__host__ __device__ inline size_t fwd_lds_floats(int upw, int t_pad, int nw, int H, int dh) {
+    return (size_t)upw * t_pad + (size_t)nw * 2 + (size_t)nw * dh + (size_t)H * dh + (size_t)round_up_i(H, 4) + 4;
+}
+
+// block -> (utterance, head block): the `arrivals` workgroups of an utterance share blockIdx % 8.
+__device__ __forceinline__ bool block_to_unit(int arrivals, int B, int& b, int& a) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    b = (k / arrivals) * 8 + xcd;
+    a = k % arrivals;
+    return b < B;
+}
+
+// ---- head stage: executed by the last-arriving workgroup of utterance b ----------------------
+// All threads of the workgroup call this (uniform control flow).  `lds` is scratch of at least
+// H*dh + round_up(H,4) floats.
+__device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* lds) {
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nthr >> 6;
+    const int H = p.H, dh = p.dh;
+    float* cb = lds;
+    float* u = lds + (size_t)H * dh;
+    const float* cg = p.ctx + (size_t)b * H * dh;
+    for (int i = tid; i < H * dh; i += nthr) cb[i] = load_agent(cg + i);
+    __syncthreads();
+    for (int hh = w; hh < H; hh += nw) {
+        float s = 0.f;
+        for (int d = lane; d < dh; d += 64) s = fmaf(cb[hh * dh + d], p.att[d], s);
+        s = group_sum<64>(s);
+        if (lane == 0) {
+            if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) s = -INFINITY;
+            u[hh] = s;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, u[hh]);
+    float den = 0.f;
+    for (int hh = 0; hh < H; ++hh) den += fast_exp2((u[hh] - mx) * kLog2e);  // all masked: NaN, as the reference
+    const float inv = 1.0f / den;
+    for (int d = tid; d < dh; d += nthr) {
+        float o = 0.f;
+        for (int hh = 0; hh < H; ++hh) o = fmaf(fast_exp2((u[hh] - mx) * kLog2e) * inv, cb[hh * dh + d], o);
+        p.out[(size_t)b * dh + d] = o;
+    }
+    if (p.head_w != nullptr)
+        for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((u[hh] - mx) * kLog2e) * inv;
+}
+
+// Arrival: every storing wave drains its write-through stores, the workgroup joins, one lane takes a
+// ticket on the utterance's counter; the workgroup that draws the last ticket runs the head stage.
+__device__ __forceinline__ void arrive_and_finish(const FwdParams& p, int b, float* lds_stage2, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == p.arrivals - 1);
+        if (last) __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave it zeroed
+        *lds_flag = last;
+    }
+    __syncthreads();
+    if (*lds_flag == 0) return;
+    head_stage(p, b, lds_stage2);
+}
+
+// ---- the streaming kernel ---------------------------------------------------------------------
+template <typename XT, int G, int NI, int R>
+__global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using E = Elem<XT>;
+    constexpr int EPV = E::kPerVec;
+    constexpr int GPW = 64 / G;
+
+    int b, a;
+    if (!block_to_unit(p.arrivals, p.B, b, a)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int wpu = p.wpu, H = p.H, dh = p.dh, T = p.T;
+    const int uu = w / wpu, wu = w - uu * wpu;
+    const int h = a * p.upw + uu;
+    const int c = lane % G, gw = lane / G;
+    const int P = wpu * GPW;
+    const int phase = wu * GPW + gw;
+    int len = T;
+    if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
+
+    float* s_lds = smem + (size_t)uu * p.t_pad;
+    float* red_ml = smem + (size_t)p.upw * p.t_pad;
+    float* red_acc = red_ml + 2 * nw;
+    float* stage2 = red_acc + (size_t)nw * dh;
+    int* flag = reinterpret_cast<int*>(stage2 + (size_t)H * dh + round_up_i(H, 4));
+
+    // query fragment, pre-scaled so that scores are in the log2 domain
+    float q[NI][EPV];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)((c + G * j) * EPV + e) * H + h] * p.qscale;
+
+    const char* xrow = static_cast<const char*>(p.x) +
+                       ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
+    const size_t row_bytes = (size_t)p.st * E::kBytes;
+
+    float m = -INFINITY, l = 0.f;
+    float acc[NI][EPV];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[j][e] = 0.f;
+
+    const int rows_per_pass = P * R;
+    const int npass = (len + rows_per_pass - 1) / rows_per_pass;
+
+    auto load_pass = [&](uint4 (&buf)[R][NI], int pass) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int t = phase + P * (pass * R + i);
+            const bool valid = t < len;
+            const char* rp = xrow + (size_t)t * row_bytes;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * G * 16);
+                buf[i][j] = v;
+            }
+        }
+    };
+
+    auto compute_pass = [&](const uint4 (&buf)[R][NI], int pass) {
+        float s[R];
+        float pm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                float f[EPV];
+                E::unpack(buf[i][j], f);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) d = fmaf(f[e], q[j][e], d);
+            }
+            d = group_sum<G>(d);
+            const int t = phase + P * (pass * R + i);
+            s[i] = (t < len) ? d : -INFINITY;
+            pm = fmaxf(pm, s[i]);
+            if (c == 0 && t < len) s_lds[t] = d;
+        }
+        const float m_new = fmaxf(m, pm);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float corr = fast_exp2(m - m_use);
+        l *= corr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[j][e] *= corr;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float pr = fast_exp2(s[i] - m_use);
+            l += pr;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                float f[EPV];
+                E::unpack(buf[i][j], f);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) acc[j][e] = fmaf(pr, f[e], acc[j][e]);
+            }
+        }
+        m = m_new;
+    };
+
+    uint4 bufA[R][NI], bufB[R][NI];
+    if (npass > 0) load_pass(bufA, 0);
+    for (int pass = 0; pass < npass; pass += 2) {
+        if (pass + 1 < npass) load_pass(bufB, pass + 1);
+        compute_pass(bufA, pass);
+        if (pass + 1 < npass) {
+            if (pass + 2 < npass) load_pass(bufA, pass + 2);
+            compute_pass(bufB, pass + 1);
+        }
+    }
+
+    // merge the groups of this wave (xor butterflies across group boundaries)
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
+        const float mn = fmaxf(m, mo);
+        const float mu = (mn == -INFINITY) ? 0.f : mn;
+        const float ca = fast_exp2(m - mu), cb = fast_exp2(mo - mu);
+        l = l * ca + lo * cb;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[j][e] = acc[j][e] * ca + __shfl_xor(acc[j][e], off) * cb;
+        m = mn;
+    }
+    if (lane < G) {
+        if (lane == 0) { red_ml[2 * w] = m; red_ml[2 * w + 1] = l; }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) red_acc[(size_t)w * dh + (c + G * j) * EPV + e] = acc[j][e];
+    }
+    __syncthreads();
+
+    // finish the unit: (M, L), context vector, alignments
+    const int w0 = uu * wpu;
+    float M = -INFINITY;
+    for (int k = 0; k < wpu; ++k) M = fmaxf(M, red_ml[2 * (w0 + k)]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f;
+    for (int k = 0; k < wpu; ++k) L += red_ml[2 * (w0 + k) + 1] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
+    const float invL = (L > 0.f) ? 1.0f / L : 0.f;
+    const int tu = wu * 64 + lane, nthr_u = wpu * 64;
+    float* cg = p.ctx + ((size_t)b * H + h) * dh;
+    for (int d = tu; d < dh; d += nthr_u) {
+        float v = 0.f;
+        for (int k = 0; k < wpu; ++k) v += red_acc[(size_t)(w0 + k) * dh + d] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
+        store_agent(cg + d, v * invL);
+    }
+    if (p.align != nullptr) {
+        float* ag = p.align + (size_t)b * T * H + h;
+        for (int t = tu; t < T; t += nthr_u) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+    }
+    if (p.ml != nullptr && tu == 0) {
+        p.ml[((size_t)b * H + h) * 2] = M;
+        p.ml[((size_t)b * H + h) * 2 + 1] = L;
+    }
+    if (p.att == nullptr) return;
+    arrive_and_finish(p, b, stage2, flag);
+}
+
+// ---- shape-agnostic kernel: any dh, any alignment, any stride ---------------------------------
+// One 256-thread workgroup per unit; lane <-> frame for the scores, lane <-> feature for the sums.
+template <typename XT>
+__global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using E = Elem<XT>;
+    int b, h;
+    if (!block_to_unit(p.arrivals, p.B, b, h)) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nw = nthr >> 6;
+    const int H = p.H, dh = p.dh, T = p.T;
+    int len = T;
+    if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
+
+    float* s_lds = smem;                       // [t_pad]
+    float* red = smem + p.t_pad;               // [2*nw]
+    float* qs = red + 2 * nw;                  // [dh] (lives in the red_acc slot: nw*dh >= dh)
+    float* stage2 = qs + (size_t)nw * dh;
+    int* flag = reinterpret_cast<int*>(stage2 + (size_t)H * dh + round_up_i(H, 4));
+
+    for (int d = tid; d < dh; d += nthr) qs[d] = p.query[(size_t)d * H + h] * p.qscale;
+    __syncthreads();
+    const long long base = (long long)b * p.sb + (long long)h * dh;
+    float mloc = -INFINITY;
+    for (int t = tid; t < len; t += nthr) {
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s = fmaf(E::load1(p.x, base + (long long)t * p.st + d), qs[d], s);
+        s_lds[t] = s;
+        mloc = fmaxf(mloc, s);
+    }
+    mloc = group_max<64>(mloc);
+    if (lane == 0) red[w] = mloc;
+    __syncthreads();
+    float M = -INFINITY;
+    for (int k = 0; k < nw; ++k) M = fmaxf(M, red[k]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float lloc = 0.f;
+    for (int t = tid; t < len; t += nthr) lloc += fast_exp2(s_lds[t] - Mu);
+    lloc = group_sum<64>(lloc);
+    if (lane == 0) red[nw + w] = lloc;
+    __syncthreads();
+    float L = 0.f;
+    for (int k = 0; k < nw; ++k) L += red[nw + k];
+    const float invL = (L > 0.f) ? 1.0f / L : 0.f;
+    float* cg = p.ctx + ((size_t)b * H + h) * dh;
+    for (int d = tid; d < dh; d += nthr) {
+        float v = 0.f;
+        for (int t = 0; t < len; ++t) v = fmaf(fast_exp2(s_lds[t] - Mu), E::load1(p.x, base + (long long)t * p.st + d), v);
+        store_agent(cg + d, v * invL);
+    }
+    if (p.align != nullptr) {
+        float* ag = p.align + (size_t)b * T * H + h;
+        for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+    }
+    if (p.ml != nullptr && tid == 0) {
+        p.ml[((size_t)b * H + h) * 2] = M;
+        p.ml[((size_t)b * H + h) * 2 + 1] = L;
+    }
+    if (p.att == nullptr) return;
+    arrive_and_finish(p, b, stage2, flag);
+}
+
+// ---- host side --------------------------------------------------------------------------------
+struct Tuning { int nw = 0, wpu = 0, lds_pad = 0, force_generic = 0; };
+static Tuning g_tuning;
+static thread_local char g_last_variant[96] = "none";
+
+constexpr int rows_per_pass_for(int ni) { return ni == 1 ? 4 : (ni <= 3 ? 2 : 1); }
+
+template <typename XT, int G, int NI>
+static hipError_t launch_vec(const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    constexpr int R = rows_per_pass_for(NI);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_fwd_vec<XT, G, NI, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((dmha_fwd_vec<XT, G, NI, R>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+template <typename XT>
+static bool dispatch_vec(int G, int NI, const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
+#define DASV_CASE(g, n) if (G == g && NI == n) { err = launch_vec<XT, g, n>(p, grid, block, lds, s); return true; }
+    DASV_CASE(16, 1) DASV_CASE(16, 2) DASV_CASE(16, 3) DASV_CASE(16, 4)
+    DASV_CASE(16, 5) DASV_CASE(16, 6) DASV_CASE(16, 7) DASV_CASE(16, 8)
+    DASV_CASE(8, 1) DASV_CASE(8, 3) DASV_CASE(8, 5) DASV_CASE(8, 7)
+    DASV_CASE(4, 1) DASV_CASE(4, 3) DASV_CASE(4, 5) DASV_CASE(4, 7)
+#undef DASV_CASE
+    return false;
+}
+
+static int largest_divisor_leq(int n, int cap) {
+    for (int d = cap; d >= 1; --d) if (n % d == 0) return d;
+    return 1;
+}
+
+template <typename XT>
+static int fwd_impl(const void* x, const float* query, const float* att, const uint8_t* keep, const int32_t* lengths,
+                    float* out, float* align, float* head_w, float* ctx, float* ml, void* workspace,
+                    size_t workspace_bytes, int B, int T, int H, int dh, int64_t sb, int64_t st, hipStream_t stream) {
+    using E = Elem<XT>;
+    if (x == nullptr || query == nullptr || ctx == nullptr) return DASV_E_NULL;
+    if (att != nullptr && out == nullptr) return DASV_E_NULL;
+    if (B <= 0 || T <= 0 || H <= 0 || dh <= 0) return DASV_E_SHAPE;
+    if ((long long)H * dh > (1ll << 24) || (long long)B > (1ll << 24)) return DASV_E_SHAPE;
+    if (st < (int64_t)H * dh || sb < 0) return DASV_E_STRIDE;
+    if (att != nullptr) {
+        if (workspace == nullptr || workspace_bytes < dasv_dmha_workspace_bytes(B, T, H, dh)) return DASV_E_WORKSPACE;
+    }
+
+    FwdParams p;
+    p.x = x; p.query = query; p.att = att; p.keep = keep; p.lengths = lengths;
+    p.out = out; p.align = align; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
+    p.counters = static_cast<int*>(workspace);
+    p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
+    p.t_pad = round_up_i(T, 4);
+    p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
+
+    // fast path needs 16-byte-aligned rows
+    const bool aligned = ((uintptr_t)x % 16 == 0) && ((sb * E::kBytes) % 16 == 0) && ((st * E::kBytes) % 16 == 0) &&
+                         (dh % E::kPerVec == 0);
+    int G = 0, NI = 0;
+    if (aligned && !g_tuning.force_generic) {
+        const int vecs = dh / E::kPerVec;
+        G = 16;
+        while (G > 1 && vecs % G != 0) G >>= 1;
+        NI = vecs / G;
+        if (G < 4 || NI > 8) G = 0;
+    }
+    const int groups8 = (B + 7) / 8 * 8;
+    if (G != 0) {
+        const int gpw = 64 / G;
+        // waves per unit: enough row phases that one unit is a handful of passes, at most 8 waves
+        int wpu = g_tuning.wpu;
+        if (wpu <= 0) {
+            const int rpp = rows_per_pass_for(NI);
+            wpu = 1;
+            while (wpu < 8 && wpu * gpw * rpp * 4 < T) wpu <<= 1;
+        }
+        if (wpu > 8) wpu = 8;
+        int nw = g_tuning.nw > 0 ? g_tuning.nw : (wpu >= 4 ? wpu : 4);
+        if (nw > 8) nw = 8;
+        if (nw < wpu) nw = wpu;
+        nw = nw / wpu * wpu;
+        int upw = largest_divisor_leq(H, nw / wpu);
+        nw = upw * wpu;
+        p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
+        const size_t lds = fwd_lds_floats(upw, p.t_pad, nw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
+        if (lds <= 160 * 1024) {
+            dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
+            hipError_t err = hipSuccess;
+            if (dispatch_vec<XT>(G, NI, p, grid, block, lds, stream, err)) {
+                snprintf(g_last_variant, sizeof(g_last_variant), "vec<dtype=%d,G=%d,NI=%d,R=%d> nw=%d wpu=%d upw=%d lds=%zu",
+                         XT::kCode, G, NI, rows_per_pass_for(NI), nw, wpu, upw, lds);
+                return (int)err;
+            }
+        }
+    }
+    // shape-agnostic path
+    p.wpu = 4; p.upw = 1; p.arrivals = H;
+    const size_t lds = fwd_lds_floats(1, p.t_pad, 4, H, dh) * sizeof(float);
+    if (lds > 160 * 1024) return DASV_E_SHAPE;
+    dim3 grid((unsigned)(groups8 * H)), block(256);
+    hipLaunchKernelGGL((dmha_fwd_generic<XT>), grid, block, lds, stream, p);
+    snprintf(g_last_variant, sizeof(g_last_variant), "generic<dtype=%d> lds=%zu", XT::kCode, lds);
+    return (int)hipGetLastError();
+}
+
+}  // namespace dasv
+
+// ---- C ABI ------------------------------------------------------------------------------------
+extern "C" {
+
+int dasv_abi_version(void) { return DASV_ABI_VERSION; }
+
+const char* dasv_error_string(int code) {
+    switch (code) {
+        case DASV_OK: return "ok";
+        case DASV_E_NULL: return "required pointer is NULL";
+        case DASV_E_SHAPE: return "shape out of range";
+        case DASV_E_WORKSPACE: return "workspace missing or too small";
+        case DASV_E_STRIDE: return "invalid stride";
+        case DASV_E_DTYPE: return "unknown element type";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh) {
+    (void)T; (void)H; (void)dh;
+    if (B <= 0) return 0;
+    return (size_t)dasv::round_up_i(B, 64) * sizeof(int);
+}
+
+int dasv_dmha_workspace_init(void* workspace, size_t workspace_bytes, dasv_stream_t stream) {
+    if (workspace == nullptr) return DASV_E_NULL;
+    return (int)hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream);
+}
+
+int dasv_dmha_fwd(int x_dtype, const void* x, const float* query, const float* att, const uint8_t* head_keep,
+                  const int32_t* lengths, float* out, float* align, float* head_w, float* ctx, float* ml,
+                  void* workspace, size_t workspace_bytes, int B, int T, int H, int dh, int64_t x_stride_b,
+                  int64_t x_stride_t, dasv_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (x_dtype) {
+        case DASV_F32:
+            return dasv::fwd_impl<dasv::F32>(x, query, att, head_keep, lengths, out, align, head_w, ctx, ml, workspace,
+                                             workspace_bytes, B, T, H, dh, x_stride_b, x_stride_t, s);
+        case DASV_BF16:
+            return dasv::fwd_impl<dasv::BF16>(x, query, att, head_keep, lengths, out, align, head_w, ctx, ml, workspace,
+                                              workspace_bytes, B, T, H, dh, x_stride_b, x_stride_t, s);
+        case DASV_F16:
+            return dasv::fwd_impl<dasv::F16>(x, query, att, head_keep, lengths, out, align, head_w, ctx, ml, workspace,
+                                             workspace_bytes, B, T, H, dh, x_stride_b, x_stride_t, s);
+        default:
+            return DASV_E_DTYPE;
+    }
+}
+
+#define DASV_TYPED(name, code, xtype)                                                                               \
+    int name(xtype x, const float* query, const float* att, const uint8_t* head_keep, const int32_t* lengths,      \
+             float* out, float* align, float* head_w, float* ctx, float* ml, void* workspace,                      \
+             size_t workspace_bytes, int B, int T, int H, int dh, int64_t x_stride_b, int64_t x_stride_t,          \
+             dasv_stream_t stream) {                                                                                \
+        return dasv_dmha_fwd(code, x, query, att, head_keep, lengths, out, align, head_w, ctx, ml, workspace,      \
+                             workspace_bytes, B, T, H, dh, x_stride_b, x_stride_t, stream);                        \
+    }
+DASV_TYPED(dasv_dmha_fwd_f32, DASV_F32, const float*)
+DASV_TYPED(dasv_dmha_fwd_bf16, DASV_BF16, const void*)
+DASV_TYPED(dasv_dmha_fwd_f16, DASV_F16, const void*)
+#undef DASV_TYPED
+
+void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic) {
+    dasv::g_tuning.nw = waves_per_group;
+    dasv::g_tuning.wpu = waves_per_head;
+    dasv::g_tuning.lds_pad = lds_pad_bytes;
+    dasv::g_tuning.force_generic = force_generic;
+}
+
+const char* dasv_debug_last_variant(void) { return dasv::g_last_variant; }
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+/*
+ * dasv_hip.h — C ABI of libdasv_hip.so: the MI355X (gfx950) hot path of
+ * fedecosta/DoubleAttentionSpeakerVerification.
+ *
+ * The reference has no FFI layer; its boundary for this path is the Python
+ * nn.Module API (scripts/poolings.py, scripts/loss.py).  Every entry point
+ * below replaces the chain of eager torch ops named next to it, takes raw
+ * device pointers and sizes, never allocates, never synchronises, never
+ * throws, and launches on the caller's stream (hipStream_t passed as void*).
+ * Return value: 0 on success, a negative DASV_E_* code for argument errors,
+ * or a positive hipError_t from the launch.
+ *
+ * All pointers are device pointers unless stated otherwise.  Tensors are
+ * borrowed for the duration of the enqueued work; nothing is retained.
+ */
+#ifndef DASV_HIP_H
+#define DASV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DASV_ABI_VERSION 1
+
+#define DASV_OK            0
+#define DASV_E_NULL       -1  /* a required pointer is NULL */
+#define DASV_E_SHAPE      -2  /* B/T/H/dh out of range or inconsistent */
+#define DASV_E_WORKSPACE  -3  /* workspace missing or too small */
+#define DASV_E_STRIDE     -4  /* negative stride / overlapping rows */
+#define DASV_E_DTYPE      -5  /* unknown element type code */
+
+/* element type of the frame embeddings x / grad_x */
+#define DASV_F32  0
+#define DASV_BF16 1
+#define DASV_F16  2
+
+typedef void* dasv_stream_t; /* hipStream_t */
+
+int dasv_abi_version(void);
+const char* dasv_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * Double multi-head attention pooling, forward.
+ * Replaces poolings.py:73-80 (innerKeyValueAttention), :100-109
+ * (MultiHeadAttention.forward), :45-51/:61-71 (HeadAttention narrow path) and
+ * :126-129 (DoubleMHA.forward) — about ten eager kernels and two x-sized
+ * temporaries — with ONE launch that reads x once.
+ *
+ *   x        [B,T,D=H*dh]  element (b,t,d) at x + b*x_stride_b + t*x_stride_t + d
+ *                          (strides in ELEMENTS; innermost dim contiguous)
+ *   query    [dh,H] f32    as stored by MultiHeadAttention.query (poolings.py:90)
+ *   att      [dh]   f32    HeadAttention.att (poolings.py:35); NULL => stop after
+ *                          the per-head stage (pooling_method 'MHA', model.py:37-38;
+ *                          with H=1 and query=att[D,1] this is poolings.py:14-27)
+ *   head_keep[B,H]  u8     train-time head mask (poolings.py:39-43), 1 = keep,
+ *                          0 = score forced to -inf; NULL => keep all (eval)
+ *   lengths  [B]    i32    valid frames per utterance (<= T); NULL => all T.
+ *                          Frames >= length get alignment 0 and do not contribute.
+ *   out      [B,dh] f32    DoubleMHA output (NULL allowed iff att is NULL)
+ *   align    [B,T,H] f32   softmax-over-time alignments (poolings.py:77); NULL => skipped
+ *   head_w   [B,H]  f32    softmax-over-heads weights (poolings.py:50); NULL => skipped
+ *   ctx      [B,H,dh] f32  per-head context vectors (poolings.py:79); REQUIRED
+ *                          (it is also the in-launch exchange buffer between heads)
+ *   ml       [B,H,2] f32   softmax statistics saved for backward: (max, sum) of the
+ *                          log2-domain scores; NULL => skipped
+ *   workspace              dasv_dmha_workspace_bytes() bytes, zeroed ONCE by
+ *                          dasv_dmha_workspace_init(); the kernel leaves it zeroed.
+ *                          Not shareable between launches that may overlap in time.
+ *
+ * Score scale is 1/sqrt(H) (poolings.py:75: d_k = query.size(-1)).
+ * A row whose heads are all masked yields NaN, as the reference does.
+ * ------------------------------------------------------------------------ */
+size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh);
+int dasv_dmha_workspace_init(void* workspace, size_t workspace_bytes, dasv_stream_t stream);
+
+int dasv_dmha_fwd(int x_dtype, const void* x, const float* query, const float* att,
+                  const uint8_t* head_keep, const int32_t* lengths,
+                  float* out, float* align, float* head_w, float* ctx, float* ml,
+                  void* workspace, size_t workspace_bytes,
+                  int B, int T, int H, int dh,
+                  int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
+
+/* typed conveniences (same semantics) */
+int dasv_dmha_fwd_f32(const float* x, const float* query, const float* att,
+                      const uint8_t* head_keep, const int32_t* lengths,
+                      float* out, float* align, float* head_w, float* ctx, float* ml,
+                      void* workspace, size_t workspace_bytes,
+                      int B, int T, int H, int dh,
+                      int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
+int dasv_dmha_fwd_bf16(const void* x, const float* query, const float* att,
+                       const uint8_t* head_keep, const int32_t* lengths,
+                       float* out, float* align, float* head_w, float* ctx, float* ml,
+                       void* workspace, size_t workspace_bytes,
+                       int B, int T, int H, int dh,
+                       int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
+int dasv_dmha_fwd_f16(const void* x, const float* query, const float* att,
+                      const uint8_t* head_keep, const int32_t* lengths,
+                      float* out, float* align, float* head_w, float* ctx, float* ml,
+                      void* workspace, size_t workspace_bytes,
+                      int B, int T, int H, int dh,
+                      int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Double multi-head attention pooling, backward (what torch autograd derives
+ * from poolings.py:73-80, 45-51, 61-71).  One pass: read x, write grad_x.
+ *
+ *   grad_out [B,dh] f32   gradient w.r.t. `out` (or, when att is NULL, grad_ctx
+ *                         [B,H,dh] is passed here and the head stage is skipped)
+ *   head_w, ctx, ml, out  as produced by the forward launch (out is unused when att is NULL)
+ *   grad_x   [B,T,D]      same dtype and strides as x
+ *   grad_query [dh,H] f32, grad_att [dh] f32: OVERWRITTEN (not accumulated)
+ *   workspace             dasv_dmha_bwd_workspace_bytes() bytes, no init needed
+ * ------------------------------------------------------------------------ */
+size_t dasv_dmha_bwd_workspace_bytes(int B, int T, int H, int dh);
+
+int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* att,
+                  const uint8_t* head_keep, const int32_t* lengths,
+                  const float* head_w, const float* ctx, const float* ml, const float* out,
+                  const float* grad_out,
+                  void* grad_x, float* grad_query, float* grad_att,
+                  void* workspace, size_t workspace_bytes,
+                  int B, int T, int H, int dh,
+                  int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
+ * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts
+ * cooperating on one (utterance, head) (0 = auto); lds_pad_bytes: extra LDS per
+ * workgroup to cap workgroups per CU (0 = none); force_generic: 1 = always take
+ * the shape-agnostic kernel.
+ * ------------------------------------------------------------------------ */
+void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic);
+/* name of the kernel variant the last dasv_dmha_fwd call on this thread selected */
+const char* dasv_debug_last_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASV_HIP_H */

@@ -1,0 +1,127 @@
+"""CPU-only checks of the host-side mirror of the reference interface: names, constructor signatures,
+state_dict contract, star-import shims, and that the compute path refuses CPU tensors (no fallback)."""
+import argparse
+import inspect
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _c3_params():
+    return argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32,
+                              mask_prob=0.3, embedding_size=400, num_spkrs=5994, scalingFactor=30.0,
+                              marginFactor=0.4, annealing=False)
+
+
+def test_state_dict_contract_matches_reference_default_config():
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    g = load_golden("g4_model")
+    p = _c3_params()
+    net = SpeakerClassifier(p, torch.device("cpu"))
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["c3_keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["c3_shapes"]]
+    assert sum(q.numel() for q in net.parameters()) == int(g["c3_nparams"]) == 21522384
+    assert [n for n, _ in net.named_parameters()] == [str(n) for n in g["c3_param_names"]]
+    assert p.feature_size == 80  # model.py:13 side effect
+
+
+@pytest.mark.parametrize("tag,fe,H,pool", [("v4", "VGG4L", 4, "DoubleMHA"), ("v3", "VGG3L", 8, "DoubleMHA"),
+                                           ("mha", "VGG4L", 4, "MHA"), ("att", "VGG4L", 4, "Attention")])
+def test_reference_state_dicts_load_strict(tag, fe, H, pool):
+    from conftest import sd_from_golden
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    g = load_golden("g4_model")
+    p = argparse.Namespace(front_end=fe, kernel_size=16, pooling_method=pool, heads_number=H, mask_prob=0.3,
+                           embedding_size=24, num_spkrs=11, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    net = SpeakerClassifier(p, torch.device("cpu"))
+    net.load_state_dict(sd_from_golden(g, tag + "_sd_"), strict=True)
+
+
+def test_constructor_and_forward_signatures():
+    from doubleattentionspeakerverification_amd import poolings, CNNs, loss, model
+    assert list(inspect.signature(poolings.DoubleMHA.__init__).parameters)[1:] == ["encoder_size", "heads_number", "mask_prob"]
+    assert inspect.signature(poolings.DoubleMHA.__init__).parameters["mask_prob"].default == 0.2
+    assert list(inspect.signature(poolings.MultiHeadAttention.__init__).parameters)[1:] == ["encoder_size", "heads_number"]
+    assert list(inspect.signature(poolings.HeadAttention.__init__).parameters)[1:] == ["encoder_size", "heads_number", "mask_prob", "attentionSmoothing"]
+    assert list(inspect.signature(poolings.DoubleMHA.forward).parameters)[:2] == ["self", "x"]
+    assert list(inspect.signature(loss.AMSoftmax.__init__).parameters)[1:] == ["in_feats", "n_classes", "m", "s", "annealing"]
+    sig = inspect.signature(model.SpeakerClassifier.forward).parameters
+    assert list(sig) == ["self", "x", "label", "step"] and sig["step"].default == 0
+    assert CNNs.getVGG4LOutputDimension(80, outputChannel=1024) == 5120
+    assert CNNs.getVGG3LOutputDimension(80, outputChannel=1024) == 10240
+    with pytest.raises(AssertionError):
+        poolings.MultiHeadAttention(10, 3)  # poolings.py:87
+    m = poolings.DoubleMHA(64, 4, mask_prob=0.3)
+    assert m.utteranceAttention.query.shape == (16, 4) and m.headsAttention.att.shape == (16, 1)
+    assert m.headsAttention.mask_prob == 3  # k = int(1/mask_prob)
+
+
+def test_compute_path_has_no_cpu_fallback():
+    from doubleattentionspeakerverification_amd import poolings
+    m = poolings.DoubleMHA(64, 4).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 5, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        poolings.Attention(8)(torch.zeros(2, 5, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        poolings.MultiHeadAttention(8, 2)(torch.zeros(2, 5, 8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "doubleattentionspeakerverification_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_amsoftmax_and_frontend_cpu_math_match_golden():
+    """AM-softmax and the VGG front-end are plain torch ops (device-agnostic); check them against the reference's
+    vectors here so the GPU run only has to confirm device numerics."""
+    from conftest import rnd, sd_from_golden
+    from doubleattentionspeakerverification_amd.loss import AMSoftmax
+    from doubleattentionspeakerverification_amd.CNNs import VGG3L, VGG4L
+    g = load_golden("g5_amsoftmax")
+    for tag, ann in (("plain", False), ("ann", True)):
+        head = AMSoftmax(24, 37, m=0.4, s=30.0, annealing=ann)
+        with torch.no_grad():
+            head.W.copy_(torch.from_numpy(g[tag + "_W"]))
+        for step in (0, 100, 5000, 1000000):
+            costh, logits = head(torch.from_numpy(g["x"]), torch.from_numpy(g["label"]), step)
+            np.testing.assert_allclose(costh.detach().numpy(), g["%s_s%d_costh" % (tag, step)], atol=1e-6)
+            np.testing.assert_allclose(logits.detach().numpy(), g["%s_s%d_logits" % (tag, step)], atol=2e-5)
+            assert abs(head.getAnnealedFactor(step) - float(g["%s_s%d_factor" % (tag, step)])) < 1e-12
+    g3 = load_golden("g3_vgg")
+    for L, cls in ((3, VGG3L), (4, VGG4L)):
+        for ks in (16, 32):
+            net = cls(ks).eval()
+            sd = {k: v for k, v in sd_from_golden(g3, "L%d_k%d_" % (L, ks)).items() if k.startswith("conv")}
+            net.load_state_dict(sd, strict=True)
+            for T in (8, 31, 50):
+                with torch.no_grad():
+                    y = net(torch.from_numpy(rnd(700 + T, 2, T, 80)))
+                ref = g3["L%d_k%d_T%d_y" % (L, ks, T)]
+                assert y.shape == ref.shape
+                np.testing.assert_allclose(y.numpy(), ref, atol=1e-5, rtol=1e-5)
+
+
+def test_scripts_shims_star_import_like_the_reference():
+    code = ("import sys; sys.path.append('./scripts/')\n"
+            "from model import *\n"
+            "from poolings import *\n"
+            "from CNNs import *\n"
+            "from loss import *\n"
+            "assert SpeakerClassifier and DoubleMHA and VGG4L and AMSoftmax and torch and nn and F\n"
+            "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
