@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterance-embeddings/sec on synthetic [B=64, T=300, 80-mel] batches.
+
+    python bench.py --gpus N --steps K --warmup W [--workload embed|pool|train] [--dtype fp32|bf16]
+
+A step is one pass of the hot path over one batch per GPU, inputs already resident in HBM:
+  embed (default)  SpeakerClassifier.getEmbedding (VGG4L/1024 front-end -> fused DoubleMHA -> fc/BN),
+                   the reference's default configuration (train.py:263-291), random-init weights.
+  pool             the fused DoubleMHA launch alone on [64,300,512], H=8 (BASELINE config 2), rotating over
+                   enough input buffers to defeat the 256 MiB Infinity Cache.
+  train            forward + AM-softmax/CE + backward + Adam step, gradients all-reduced over RCCL (config 4).
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); every rank processes its own batch
+(weak scaling, replicas only for embed/pool — the path has no data exchange — and one gradient all-reduce
+per step for train).  Rank 0 prints ONE JSON line.
+
+`roofline` describes the fused DoubleMHA kernel (HBM-bound): algorithmic bytes per launch over its
+average duration measured with events on the launch stream inside the timed region.  `cpu_baseline` times the
+op-sequence-faithful CPU restatement (oracle/, kind "port") on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def default_params():
+    return argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32,
+                              mask_prob=0.3, embedding_size=400, num_spkrs=5994, scalingFactor=30.0,
+                              marginFactor=0.4, annealing=False)
+
+
+def pooling_bytes(B, T, D, H, esize, with_align):
+    """read x once + write alignments + output + parameters."""
+    dh = D // H
+    return esize * B * T * D + (4 * B * T * H if with_align else 0) + 4 * B * dh + 4 * (dh * H + dh)
+
+
+class PoolTimer:
+    """Events around every fused-pooling forward launch inside the timed region, recorded on the stream the
+    kernel is launched on (the host-side wrapper `poolings._launch_fwd` is what every module path calls)."""
+
+    def __init__(self, poolings):
+        self.pairs = []
+        self.active = False
+        inner = poolings._launch_fwd
+
+        def timed(x, *a, **k):
+            if not self.active:
+                return inner(x, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(torch.cuda.current_stream(x.device))
+            r = inner(x, *a, **k)
+            e.record(torch.cuda.current_stream(x.device))
+            self.pairs.append((s, e))
+            return r
+        poolings._launch_fwd = timed
+
+    def mean_us(self):
+        d = [s.elapsed_time(e) * 1e3 for s, e in self.pairs]
+        return float(np.mean(d)) if d else None
+
+
+def cpu_baseline_embed(params, frames, seconds=12.0):
+    import oracle
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(params, torch.device("cpu")).eval()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    rs = np.random.RandomState(1234)
+    Bc = 4
+    x = torch.from_numpy(rs.standard_normal((Bc, frames, 80)).astype(np.float32))
+    n_blocks = 4 if params.front_end == "VGG4L" else 3
+    with torch.no_grad():
+        oracle.embedding_forward(x[:1], sd, n_blocks, params.heads_number)  # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            oracle.embedding_forward(x, sd, n_blocks, params.heads_number)
+            n += Bc
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d utterances of [%d,80] through oracle.embedding_forward (torch CPU fp32, op-sequence "
+                       "restatement of model.py:52-59), %.1f s" % (n, frames, dt))
+
+
+def cpu_baseline_pool(B, T, D, H, seconds=10.0):
+    import oracle
+    rs = np.random.RandomState(1234)
+    dh = D // H
+    x = torch.from_numpy(rs.standard_normal((B, T, D)).astype(np.float32))
+    q = torch.from_numpy((rs.standard_normal((dh, H)) * np.sqrt(2.0 / (dh + H))).astype(np.float32))
+    a = torch.from_numpy((rs.standard_normal((dh, 1)) * np.sqrt(2.0 / (dh + 1))).astype(np.float32))
+    with torch.no_grad():
+        oracle.dmha_opseq(x, q, a)
+        t0, n = time.perf_counter(), 0
+        while True:
+            oracle.dmha_opseq(x, q, a)
+            n += B
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d utterances of [%d,%d] through oracle.dmha_opseq (torch CPU fp32, the reference's op "
+                       "sequence poolings.py:73-80,45-51), %.1f s" % (n, T, D, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    from doubleattentionspeakerverification_amd import _lib, poolings
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    lib = _lib.load()  # raises if the HIP library is missing
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B, T = args.batch, args.frames
+    rs = np.random.RandomState(1234 + rank)
+    timer = PoolTimer(poolings)
+    compute_dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    config = {}
+
+    if args.workload == "pool":
+        D, H = 512, 8
+        dh = D // H
+        esize = 4 if compute_dtype == torch.float32 else 2
+        nbuf = max(8, int(np.ceil(300e6 / (B * T * D * esize))))
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        xs = [torch.randn(B, T, D, device=dev, generator=g).to(compute_dtype) for _ in range(nbuf)]
+        mod = poolings.DoubleMHA(D, H).to(dev).eval()
+        pool_shape = (B, T, D, H)
+        with_align = True
+
+        def step(i):
+            with torch.no_grad():
+                return mod(xs[i % nbuf])[0]
+        config = {"workload": "DoubleMHA pooling only, B=%d T=%d D=%d heads=%d (BASELINE config 2)" % (B, T, D, H),
+                  "global_batch": B * world, "frames": T, "input_buffers_rotated": nbuf, "parallelism": "replicas x%d" % world}
+    else:
+        params = default_params()
+        torch.manual_seed(1234)
+        net = SpeakerClassifier(params, dev).to(dev)
+        x = torch.from_numpy((2.0 * rs.standard_normal((B, T, 80))).astype(np.float32))
+        x = (x - x.mean(dim=1, keepdim=True)).to(dev)  # CMN, as featureExtractor.py:25-26
+        Tp = T
+        for _ in range(4):
+            Tp = (Tp + 1) // 2
+        pool_shape = (B, Tp, 5120, 32)
+        esize = 4 if compute_dtype == torch.float32 else 2
+        with_align = False
+        if args.workload == "embed":
+            net.eval()
+
+            def step(i):
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(compute_dtype == torch.bfloat16)):
+                    return net.getEmbedding(x)
+            config = {"workload": "SpeakerClassifier.getEmbedding, VGG4L/1024 + DoubleMHA(32 heads) + fc, emb 400, "
+                                  "input [%d,%d,80] per GPU (reference default config, train.py:263-291)" % (B, T),
+                      "global_batch": B * world, "frames": T, "parallelism": "replicas x%d (no data exchange)" % world}
+        else:
+            from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
+            net.train()
+            labels = torch.from_numpy(rs.randint(0, params.num_spkrs, size=(B,))).to(dev)
+            trainer = DataParallelTrainer(net, lr=1e-4, weight_decay=1e-3, autocast_dtype=(None if compute_dtype == torch.float32 else torch.bfloat16))
+
+            def step(i):
+                return trainer.train_step(x, labels, step=i)
+            config = {"workload": "training step: forward + AM-softmax/CE + backward + Adam, input [%d,%d,80] per GPU, "
+                                  "5994 speakers (BASELINE config 3/4)" % (B, T),
+                      "global_batch": B * world, "frames": T, "parallelism": "dp%d (RCCL all-reduce of flat fp32 gradients)" % world}
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    timer.active = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.active = False
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        Bp, Tp, Dp, Hp = pool_shape
+        abytes = pooling_bytes(Bp, Tp, Dp, Hp, esize, with_align)
+        pool_us = timer.mean_us()
+        roofline = None
+        if pool_us:
+            ach = abytes / pool_us / 1e3  # GB/s
+            roofline = {"kernel": "dasv::dmha_fwd_vec (fused DoubleMHA forward)", "bound": "hbm", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(pool_us, 3),
+                        "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_debug_last_variant().decode()}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(os.cpu_count() or 1)
+            cpu = cpu_baseline_pool(B, T, 512, 8) if args.workload == "pool" else cpu_baseline_embed(default_params(), T)
+        out = {
+            "metric": "utterance-embeddings/sec" if args.workload != "train" else "training utterances/sec",
+            "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "utterance-embeddings/s" if args.workload != "train" else "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if compute_dtype == torch.float32 else "bf16",
+            "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
+            "config": config, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,7 @@ struct FwdParams {
     float* ctx;            // [B,H,dh]
     float* ml;             // [B,H,2] or null
     int* counters;         // [B] arrival counters (zero between launches)
+    float* exch_u;         // [B][round_up(H,4)] head scores <c_h, att>, published beside ctx
     long long sb, st;      // element strides of x
     int B, T, H, dh;
     int wpu;               // waves cooperating on one unit
@@ -51,11 +52,24 @@ struct FwdParams {
     int arrivals;          // workgroups per utterance = H / upw
     int t_pad;             // LDS score row pitch (floats)
     float qscale;          // log2(e) / sqrt(H)
+#ifdef DASV_STAMPS
+    unsigned long long* stamps;  // diagnostic build only: [gridDim.x][8] s_memrealtime stamps (100 MHz)
+#endif
 };
 
-// LDS carve (floats): [upw][t_pad] scores | [NW][2] (m,l) | [NW][dh] acc | [H][dh] ctx copy | [H] u | flag
+#ifdef DASV_STAMPS
+#define DASV_STAMP(p, k)                                                                          \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && (p).stamps != nullptr)                                            \
+            (p).stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();          \
+    } while (0)
+#else
+#define DASV_STAMP(p, k) do { } while (0)
+#endif
+
+// LDS carve (floats): [upw][t_pad] scores | [NW][2] (m,l) | [NW][dh] acc | [round_up(H,4)] head scores | flag
 __host__ __device__ inline size_t fwd_lds_floats(int upw, int t_pad, int nw, int H, int dh) {
-    return (size_t)upw * t_pad + (size_t)nw * 2 + (size_t)nw * dh + (size_t)H * dh + (size_t)round_up_i(H, 4) + 4;
+    return (size_t)upw * t_pad + (size_t)nw * 2 + (size_t)nw * dh + (size_t)round_up_i(H, 4) + 4;
 }
 
 // block -> (utterance, head block): the `arrivals` workgroups of an utterance share blockIdx % 8.
@@ -67,54 +81,105 @@ __device__ __forceinline__ bool block_to_unit(int arrivals, int B, int& b, int& 
 }
 
 // ---- head stage: executed by the last-arriving workgroup of utterance b ----------------------
-// All threads of the workgroup call this (uniform control flow).  `lds` is scratch of at least
-// H*dh + round_up(H,4) floats.
-__device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* lds) {
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, nw = nthr >> 6;
-    const int H = p.H, dh = p.dh;
-    float* cb = lds;
-    float* u = lds + (size_t)H * dh;
+// Every workgroup has already published its context vector c_h (ctx, write-through) and its head score
+// u_h = <c_h, att> (exch_u, write-through).  The last arriver reads the H scores and the H vectors with
+// agent-scope (L1-bypassing) loads only, applies the train-time mask, and writes out / head_w.
+// All threads of the workgroup call this (uniform control flow).  `us` is LDS scratch of >= H floats.
+template <bool VEC4>
+__device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* us) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int H = p.H, dh = p.dh, hpad = round_up_i(H, 4);
+    const float* ug = p.exch_u + (size_t)b * hpad;
     const float* cg = p.ctx + (size_t)b * H * dh;
-    for (int i = tid; i < H * dh; i += nthr) cb[i] = load_agent(cg + i);
-    __syncthreads();
-    for (int hh = w; hh < H; hh += nw) {
-        float s = 0.f;
-        for (int d = lane; d < dh; d += 64) s = fmaf(cb[hh * dh + d], p.att[d], s);
-        s = group_sum<64>(s);
-        if (lane == 0) {
-            if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) s = -INFINITY;
-            u[hh] = s;
+    for (int hh = tid; hh < H; hh += nthr) {
+        float v = load_agent(ug + hh);
+        if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) v = -INFINITY;
+        us[hh] = v;
+    }
+    constexpr int CH = 8;  // context vectors fetched per round (independent loads in flight per lane)
+    if constexpr (VEC4) {
+        const int nvec = dh >> 2;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cg), 0, H * dh * 4, 0x00020000);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 cv[CH];
+        const int d4 = tid;
+        if (d4 < nvec) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (k < H) cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k * dh + d4 * 4) * 4, 0, 16));
         }
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, us[hh]);
+        float den = 0.f;
+        for (int hh = 0; hh < H; ++hh) den += fast_exp2((us[hh] - mx) * kLog2e);  // all masked: NaN, as the reference
+        const float inv = 1.0f / den;
+        for (int v0 = 0; v0 < nvec; v0 += nthr) {
+            const int dv = v0 + tid;
+            if (dv < nvec) {
+                f4 o = {0.f, 0.f, 0.f, 0.f};
+                for (int h0 = 0; h0 < H; h0 += CH) {
+                    if (v0 != 0 || h0 != 0) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k)
+                            if (h0 + k < H)
+                                cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((h0 + k) * dh + dv * 4) * 4, 0, 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (h0 + k < H) {
+                            const float wk = fast_exp2((us[h0 + k] - mx) * kLog2e) * inv;
+                            o += wk * cv[k];
+                        }
+                }
+                *reinterpret_cast<f4*>(p.out + (size_t)b * dh + dv * 4) = o;
+            }
+        }
+        if (p.head_w != nullptr)
+            for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((us[hh] - mx) * kLog2e) * inv;
+    } else {
+        __syncthreads();
+        float mx = -INFINITY;
+        for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, us[hh]);
+        float den = 0.f;
+        for (int hh = 0; hh < H; ++hh) den += fast_exp2((us[hh] - mx) * kLog2e);
+        const float inv = 1.0f / den;
+        for (int d = tid; d < dh; d += nthr) {
+            float o = 0.f;
+            for (int hh = 0; hh < H; ++hh) o = fmaf(fast_exp2((us[hh] - mx) * kLog2e) * inv, load_agent(cg + (size_t)hh * dh + d), o);
+            p.out[(size_t)b * dh + d] = o;
+        }
+        if (p.head_w != nullptr)
+            for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((us[hh] - mx) * kLog2e) * inv;
     }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, u[hh]);
-    float den = 0.f;
-    for (int hh = 0; hh < H; ++hh) den += fast_exp2((u[hh] - mx) * kLog2e);  // all masked: NaN, as the reference
-    const float inv = 1.0f / den;
-    for (int d = tid; d < dh; d += nthr) {
-        float o = 0.f;
-        for (int hh = 0; hh < H; ++hh) o = fmaf(fast_exp2((u[hh] - mx) * kLog2e) * inv, cb[hh * dh + d], o);
-        p.out[(size_t)b * dh + d] = o;
-    }
-    if (p.head_w != nullptr)
-        for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((u[hh] - mx) * kLog2e) * inv;
 }
 
-// Arrival: every storing wave drains its write-through stores, the workgroup joins, one lane takes a
-// ticket on the utterance's counter; the workgroup that draws the last ticket runs the head stage.
-__device__ __forceinline__ void arrive_and_finish(const FwdParams& p, int b, float* lds_stage2, int* lds_flag) {
+// Publication, step 1 (before the alignment stores): every wave drains its write-through stores of
+// ctx / exch_u, the workgroup joins, ONE lane takes a ticket on the utterance's arrival counter.
+// Returns the ticket (meaningful in thread 0 only); its latency hides behind the alignment stores.
+__device__ __forceinline__ int arrive(const FwdParams& p, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DASV_STAMP(p, 4);
+    int ticket = 0;
+    if (threadIdx.x == 0)
+        ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ticket;
+}
+
+// Publication, step 2: the workgroup that drew the last ticket runs the head stage.
+template <bool VEC4>
+__device__ __forceinline__ void finish_if_last(const FwdParams& p, int b, int ticket, float* lds_us, int* lds_flag) {
     if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (ticket == p.arrivals - 1);
         if (last) __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave it zeroed
         *lds_flag = last;
     }
     __syncthreads();
+    DASV_STAMP(p, 5);
     if (*lds_flag == 0) return;
-    head_stage(p, b, lds_stage2);
+    head_stage<VEC4>(p, b, lds_us);
 }
 
 // ---- the streaming kernel ---------------------------------------------------------------------
@@ -142,7 +207,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     float* red_ml = smem + (size_t)p.upw * p.t_pad;
     float* red_acc = red_ml + 2 * nw;
     float* stage2 = red_acc + (size_t)nw * dh;
-    int* flag = reinterpret_cast<int*>(stage2 + (size_t)H * dh + round_up_i(H, 4));
+    int* flag = reinterpret_cast<int*>(stage2 + round_up_i(H, 4));
 
     // query fragment, pre-scaled so that scores are in the log2 domain
     float q[NI][EPV];
@@ -150,6 +215,12 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)((c + G * j) * EPV + e) * H + h] * p.qscale;
+
+    // head-attention vector for the unit's first wave (used after the stream; fetched now to hide its latency)
+    constexpr int ND = (G * NI * EPV + 63) / 64;
+    float attv[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) attv[k] = (p.att != nullptr && wu == 0 && lane + 64 * k < dh) ? p.att[lane + 64 * k] : 0.f;
 
     const char* xrow = static_cast<const char*>(p.x) +
                        ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
@@ -222,16 +293,19 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         m = m_new;
     };
 
+    DASV_STAMP(p, 0);
     uint4 bufA[R][NI], bufB[R][NI];
     if (npass > 0) load_pass(bufA, 0);
     for (int pass = 0; pass < npass; pass += 2) {
         if (pass + 1 < npass) load_pass(bufB, pass + 1);
         compute_pass(bufA, pass);
+        if (pass == 0) DASV_STAMP(p, 1);
         if (pass + 1 < npass) {
             if (pass + 2 < npass) load_pass(bufA, pass + 2);
             compute_pass(bufB, pass + 1);
         }
     }
+    DASV_STAMP(p, 2);
 
     // merge the groups of this wave (xor butterflies across group boundaries)
 #pragma unroll
@@ -256,7 +330,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     }
     __syncthreads();
 
-    // finish the unit: (M, L), context vector, alignments
+    // finish the unit: (M, L) by every thread; context vector + head score by the unit's first wave
     const int w0 = uu * wpu;
     float M = -INFINITY;
     for (int k = 0; k < wpu; ++k) M = fmaxf(M, red_ml[2 * (w0 + k)]);
@@ -264,23 +338,40 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     float L = 0.f;
     for (int k = 0; k < wpu; ++k) L += red_ml[2 * (w0 + k) + 1] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
-    const int tu = wu * 64 + lane, nthr_u = wpu * 64;
-    float* cg = p.ctx + ((size_t)b * H + h) * dh;
-    for (int d = tu; d < dh; d += nthr_u) {
-        float v = 0.f;
-        for (int k = 0; k < wpu; ++k) v += red_acc[(size_t)(w0 + k) * dh + d] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
-        store_agent(cg + d, v * invL);
+    if (wu == 0) {
+        float* cg = p.ctx + ((size_t)b * H + h) * dh;
+        float upart = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd) {
+            const int d = lane + 64 * kd;
+            if (d < dh) {
+                float v = 0.f;
+                for (int k = 0; k < wpu; ++k) v += red_acc[(size_t)(w0 + k) * dh + d] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
+                v *= invL;
+                store_agent(cg + d, v);
+                upart = fmaf(v, attv[kd], upart);
+            }
+        }
+        if (p.att != nullptr) {
+            upart = group_sum<64>(upart);
+            if (lane == 0) store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, upart);
+        }
+        if (p.ml != nullptr && lane == 0) {
+            p.ml[((size_t)b * H + h) * 2] = M;
+            p.ml[((size_t)b * H + h) * 2 + 1] = L;
+        }
     }
+    DASV_STAMP(p, 3);
+    int ticket = 0;
+    if (p.att != nullptr) ticket = arrive(p, b);
     if (p.align != nullptr) {
+        const int tu = wu * 64 + lane, nthr_u = wpu * 64;
         float* ag = p.align + (size_t)b * T * H + h;
         for (int t = tu; t < T; t += nthr_u) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
     }
-    if (p.ml != nullptr && tu == 0) {
-        p.ml[((size_t)b * H + h) * 2] = M;
-        p.ml[((size_t)b * H + h) * 2 + 1] = L;
-    }
     if (p.att == nullptr) return;
-    arrive_and_finish(p, b, stage2, flag);
+    finish_if_last<true>(p, b, ticket, stage2, flag);
+    DASV_STAMP(p, 6);
 }
 
 // ---- shape-agnostic kernel: any dh, any alignment, any stride ---------------------------------
@@ -300,7 +391,7 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     float* red = smem + p.t_pad;               // [2*nw]
     float* qs = red + 2 * nw;                  // [dh] (lives in the red_acc slot: nw*dh >= dh)
     float* stage2 = qs + (size_t)nw * dh;
-    int* flag = reinterpret_cast<int*>(stage2 + (size_t)H * dh + round_up_i(H, 4));
+    int* flag = reinterpret_cast<int*>(stage2 + round_up_i(H, 4));
 
     for (int d = tid; d < dh; d += nthr) qs[d] = p.query[(size_t)d * H + h] * p.qscale;
     __syncthreads();
@@ -327,33 +418,52 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     for (int k = 0; k < nw; ++k) L += red[nw + k];
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
     float* cg = p.ctx + ((size_t)b * H + h) * dh;
+    float upart = 0.f;
     for (int d = tid; d < dh; d += nthr) {
         float v = 0.f;
         for (int t = 0; t < len; ++t) v = fmaf(fast_exp2(s_lds[t] - Mu), E::load1(p.x, base + (long long)t * p.st + d), v);
-        store_agent(cg + d, v * invL);
+        v *= invL;
+        store_agent(cg + d, v);
+        if (p.att != nullptr) upart = fmaf(v, p.att[d], upart);
     }
-    if (p.align != nullptr) {
-        float* ag = p.align + (size_t)b * T * H + h;
-        for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+    if (p.att != nullptr) {   // head score <c_h, att>: waves -> LDS -> thread 0
+        upart = group_sum<64>(upart);
+        __syncthreads();      // everyone is done with red[] from the sum pass
+        if (lane == 0) red[w] = upart;
+        __syncthreads();
+        if (tid == 0) {
+            float u = 0.f;
+            for (int k = 0; k < nw; ++k) u += red[k];
+            store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, u);
+        }
     }
     if (p.ml != nullptr && tid == 0) {
         p.ml[((size_t)b * H + h) * 2] = M;
         p.ml[((size_t)b * H + h) * 2 + 1] = L;
     }
+    int ticket = 0;
+    if (p.att != nullptr) ticket = arrive(p, b);
+    if (p.align != nullptr) {
+        float* ag = p.align + (size_t)b * T * H + h;
+        for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+    }
     if (p.att == nullptr) return;
-    arrive_and_finish(p, b, stage2, flag);
+    if ((dh & 3) == 0) finish_if_last<true>(p, b, ticket, stage2, flag);
+    else finish_if_last<false>(p, b, ticket, stage2, flag);
 }
 
 // ---- host side --------------------------------------------------------------------------------
-struct Tuning { int nw = 0, wpu = 0, lds_pad = 0, force_generic = 0; };
+struct Tuning { int nw = 0, wpu = 0, lds_pad = 0, force_generic = 0, rows = 0; };
+#ifdef DASV_STAMPS
+static unsigned long long* g_stamps = nullptr;
+#endif
 static Tuning g_tuning;
 static thread_local char g_last_variant[96] = "none";
 
 constexpr int rows_per_pass_for(int ni) { return ni == 1 ? 4 : (ni <= 3 ? 2 : 1); }
 
-template <typename XT, int G, int NI>
+template <typename XT, int G, int NI, int R>
 static hipError_t launch_vec(const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    constexpr int R = rows_per_pass_for(NI);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_fwd_vec<XT, G, NI, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -363,13 +473,15 @@ static hipError_t launch_vec(const FwdParams& p, dim3 grid, dim3 block, size_t l
     return hipGetLastError();
 }
 
+// (G, NI) -> kernel; R (rows per lane per pass) defaults per NI, a few alternatives exist for sweeps.
 template <typename XT>
-static bool dispatch_vec(int G, int NI, const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
-#define DASV_CASE(g, n) if (G == g && NI == n) { err = launch_vec<XT, g, n>(p, grid, block, lds, s); return true; }
-    DASV_CASE(16, 1) DASV_CASE(16, 2) DASV_CASE(16, 3) DASV_CASE(16, 4)
-    DASV_CASE(16, 5) DASV_CASE(16, 6) DASV_CASE(16, 7) DASV_CASE(16, 8)
-    DASV_CASE(8, 1) DASV_CASE(8, 3) DASV_CASE(8, 5) DASV_CASE(8, 7)
-    DASV_CASE(4, 1) DASV_CASE(4, 3) DASV_CASE(4, 5) DASV_CASE(4, 7)
+static bool dispatch_vec(int G, int NI, int R, const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
+#define DASV_CASE(g, n, r) if (G == g && NI == n && R == r) { err = launch_vec<XT, g, n, r>(p, grid, block, lds, s); return true; }
+    DASV_CASE(16, 1, 4) DASV_CASE(16, 1, 2) DASV_CASE(16, 1, 8)
+    DASV_CASE(16, 2, 2) DASV_CASE(16, 2, 4) DASV_CASE(16, 3, 2) DASV_CASE(16, 4, 1) DASV_CASE(16, 4, 2)
+    DASV_CASE(16, 5, 1) DASV_CASE(16, 5, 2) DASV_CASE(16, 6, 1) DASV_CASE(16, 7, 1) DASV_CASE(16, 8, 1)
+    DASV_CASE(8, 1, 4) DASV_CASE(8, 1, 8) DASV_CASE(8, 3, 2) DASV_CASE(8, 5, 1) DASV_CASE(8, 5, 2) DASV_CASE(8, 7, 1)
+    DASV_CASE(4, 1, 4) DASV_CASE(4, 1, 8) DASV_CASE(4, 3, 2) DASV_CASE(4, 5, 1) DASV_CASE(4, 5, 2) DASV_CASE(4, 7, 1)
 #undef DASV_CASE
     return false;
 }
@@ -397,9 +509,13 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     p.x = x; p.query = query; p.att = att; p.keep = keep; p.lengths = lengths;
     p.out = out; p.align = align; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
     p.counters = static_cast<int*>(workspace);
+    p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)round_up_i(B, 64) * sizeof(int));
     p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
+#ifdef DASV_STAMPS
+    p.stamps = g_stamps;
+#endif
 
     // fast path needs 16-byte-aligned rows
     const bool aligned = ((uintptr_t)x % 16 == 0) && ((sb * E::kBytes) % 16 == 0) && ((st * E::kBytes) % 16 == 0) &&
@@ -416,27 +532,33 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     if (G != 0) {
         const int gpw = 64 / G;
         // waves per unit: enough row phases that one unit is a handful of passes, at most 8 waves
+        int R = rows_per_pass_for(NI);
+        // waves per unit: enough row phases that a unit is about five passes; workgroups of up to 8 waves
+        // that carry several heads of one utterance (fewer arrivals), but never fewer workgroups than CUs.
         int wpu = g_tuning.wpu;
         if (wpu <= 0) {
-            const int rpp = rows_per_pass_for(NI);
             wpu = 1;
-            while (wpu < 8 && wpu * gpw * rpp * 4 < T) wpu <<= 1;
+            while (wpu < 8 && wpu * gpw * R * 5 < T) wpu <<= 1;
         }
         if (wpu > 8) wpu = 8;
-        int nw = g_tuning.nw > 0 ? g_tuning.nw : (wpu >= 4 ? wpu : 4);
+        int nw = g_tuning.nw > 0 ? g_tuning.nw : 8;
         if (nw > 8) nw = 8;
         if (nw < wpu) nw = wpu;
-        nw = nw / wpu * wpu;
         int upw = largest_divisor_leq(H, nw / wpu);
+        if (g_tuning.nw <= 0)
+            while (upw > 1 && (long long)groups8 * (H / upw) < 256) upw = largest_divisor_leq(H, upw - 1);
         nw = upw * wpu;
         p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
         const size_t lds = fwd_lds_floats(upw, p.t_pad, nw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
         if (lds <= 160 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
             hipError_t err = hipSuccess;
-            if (dispatch_vec<XT>(G, NI, p, grid, block, lds, stream, err)) {
+            bool ok = g_tuning.rows > 0 && dispatch_vec<XT>(G, NI, g_tuning.rows, p, grid, block, lds, stream, err);
+            if (ok) R = g_tuning.rows;
+            else ok = dispatch_vec<XT>(G, NI, R, p, grid, block, lds, stream, err);
+            if (ok) {
                 snprintf(g_last_variant, sizeof(g_last_variant), "vec<dtype=%d,G=%d,NI=%d,R=%d> nw=%d wpu=%d upw=%d lds=%zu",
-                         XT::kCode, G, NI, rows_per_pass_for(NI), nw, wpu, upw, lds);
+                         XT::kCode, G, NI, R, nw, wpu, upw, lds);
                 return (int)err;
             }
         }
@@ -471,9 +593,10 @@ const char* dasv_error_string(int code) {
 }
 
 size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh) {
-    (void)T; (void)H; (void)dh;
-    if (B <= 0) return 0;
-    return (size_t)dasv::round_up_i(B, 64) * sizeof(int);
+    (void)T; (void)dh;
+    if (B <= 0 || H <= 0) return 0;
+    // [round_up(B,64)] arrival counters (must be zero between launches) | [B][round_up(H,4)] head scores
+    return (size_t)dasv::round_up_i(B, 64) * sizeof(int) + (size_t)B * dasv::round_up_i(H, 4) * sizeof(float);
 }
 
 int dasv_dmha_workspace_init(void* workspace, size_t workspace_bytes, dasv_stream_t stream) {
@@ -514,7 +637,9 @@ DASV_TYPED(dasv_dmha_fwd_bf16, DASV_BF16, const void*)
 DASV_TYPED(dasv_dmha_fwd_f16, DASV_F16, const void*)
 #undef DASV_TYPED
 
-void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic) {
+void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic,
+                           int rows_per_pass) {
+    dasv::g_tuning.rows = rows_per_pass;
     dasv::g_tuning.nw = waves_per_group;
     dasv::g_tuning.wpu = waves_per_head;
     dasv::g_tuning.lds_pad = lds_pad_bytes;
@@ -522,5 +647,9 @@ void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_
 }
 
 const char* dasv_debug_last_variant(void) { return dasv::g_last_variant; }
+
+#ifdef DASV_STAMPS
+void dasv_debug_set_stamps(void* p) { dasv::g_stamps = static_cast<unsigned long long*>(p); }
+#endif
 
 }  // extern "C"

@@ -1,0 +1,206 @@
+"""Data-parallel training for the speaker classifier: one process per GPU, RCCL over xGMI.
+
+Replaces the reference's single-process ``nn.DataParallel`` wrap (train.py:63-70), which re-broadcasts all
+21.5 M parameters (86 MB) to every GPU on every forward and reduces gradients onto GPU 0 each backward.
+Here parameters stay resident on every rank and the ONLY per-step traffic is one all-reduce of the flat
+fp32 gradient buffer, cut into buckets that are launched from autograd hooks as soon as their gradients
+exist, so the reduction of the big late-layer tensors (conv42/conv41, 56 MB) overlaps the rest of backward.
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): a few large buckets keep every link busy;
+many small ones would be launch-bound.
+
+Step semantics follow train.py:215-226: cross-entropy is a mean over the GLOBAL batch (equal shards =>
+mean of rank means => gradients are averaged over ranks); gradient accumulation SUMS micro-batch
+gradients (no division); the optimizer is Adam(lr, weight_decay) / SGD / RMSprop as train.py:82-88.
+Parameters that never receive a gradient (b1.*, b3.* — model.py:46,50) keep a zero slot in the buffer and
+are hidden from the optimizer (grad None), so like in the reference they get no update and no weight decay.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+__all__ = ["init_distributed", "FlatGradReducer", "DataParallelTrainer", "shard_batch"]
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if use_gpu else "gloo")  # "nccl" IS RCCL on ROCm
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def shard_batch(n_items, rank, world):
+    """Contiguous equal shard [lo, hi) of a global batch; requires divisibility so the CE mean stays global."""
+    if n_items % world != 0:
+        raise ValueError("global batch %d is not divisible by %d ranks" % (n_items, world))
+    per = n_items // world
+    return rank * per, (rank + 1) * per
+
+
+class FlatGradReducer:
+    """All parameter gradients live in ONE contiguous fp32 buffer; buckets of it are all-reduced
+    asynchronously the moment every gradient in the bucket has been accumulated."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, torch.float32
+        sizes = [p.numel() for p in self.params]
+        # 64-element (256 B) aligned slots, laid out in REVERSE registration order: backward produces the
+        # gradients of the last layers first, so bucket 0 fills first.
+        order = list(range(len(self.params)))[::-1]
+        offs, total = {}, 0
+        for i in order:
+            offs[i] = total
+            total += (sizes[i] + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.buckets = []  # (lo, hi, [param indices])
+        cap = max(1, bucket_bytes // 4)
+        lo, members = 0, []
+        for i in order:
+            members.append(i)
+            hi = offs[i] + (sizes[i] + 63) // 64 * 64
+            if hi - lo >= cap:
+                self.buckets.append((lo, hi, members))
+                lo, members = hi, []
+        if members:
+            self.buckets.append((lo, total, members))
+        self.bucket_of = {}
+        for bi, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self.bucket_of[i] = bi
+        self.views = []
+        for i, p in enumerate(self.params):
+            if p.dtype != dt:
+                raise TypeError("FlatGradReducer expects fp32 master parameters")
+            self.views.append(self.flat[offs[i]:offs[i] + sizes[i]].view_as(p))
+            p.grad = self.views[i]
+        self._fired = [False] * len(self.params)
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._armed = False
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            self._fired[i] = True
+            if not self._armed:
+                return
+            bi = self.bucket_of[i]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        if self._launched[bi] or self.world == 1:
+            self._launched[bi] = True
+            return
+        lo, hi, _ = self.buckets[bi]
+        self._launched[bi] = True
+        self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def arm(self):
+        """Call before the backward pass whose gradients are to be reduced (the LAST micro-batch)."""
+        self._armed = True
+        self._pending = [len(mem) for _, _, mem in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def finish(self):
+        """After backward: reduce buckets whose hooks never all fired (unused parameters), wait, average."""
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._armed = False
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+
+    def zero(self):
+        self.flat.zero_()
+        self._fired = [False] * len(self.params)
+
+    def hide_unused(self):
+        """Parameters that received no gradient since the last zero() must look like `grad is None` to the
+        optimizer, exactly as in the reference (b1.*, b3.*: no update, no weight decay)."""
+        hidden = [i for i, f in enumerate(self._fired) if not f]
+        for i in hidden:
+            self.params[i].grad = None
+        return hidden
+
+    def restore(self, hidden):
+        for i in hidden:
+            self.params[i].grad = self.views[i]
+
+
+class DataParallelTrainer:
+    """One training step per call, with the reference's step semantics (train.py:186-198, 215-226)."""
+
+    def __init__(self, net, lr=1e-4, weight_decay=1e-3, optimizer="Adam", accum=1, bucket_bytes=32 << 20,
+                 autocast_dtype=None, group=None):
+        self.net = net
+        self.accum = int(accum)
+        self.autocast_dtype = autocast_dtype
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world > 1:
+            self.broadcast_state()
+        self.reducer = FlatGradReducer(net.parameters(), bucket_bytes=bucket_bytes, group=group)
+        params = list(net.parameters())
+        on_gpu = params[0].is_cuda
+        if optimizer == "Adam":
+            self.opt = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=on_gpu)
+        elif optimizer == "SGD":
+            self.opt = torch.optim.SGD(params, lr=lr, weight_decay=weight_decay)
+        elif optimizer == "RMSprop":
+            self.opt = torch.optim.RMSprop(params, lr=lr, weight_decay=weight_decay)
+        else:
+            raise ValueError(optimizer)
+        self.criterion = nn.CrossEntropyLoss()
+        self._micro = 0
+
+    def broadcast_state(self):
+        """Rank 0's parameters and buffers to everyone (initialisation, and what DataParallel's
+        keep-GPU-0's-BatchNorm-statistics behaviour amounts to at checkpoint time)."""
+        for t in list(self.net.parameters()) + list(self.net.buffers()):
+            dist.broadcast(t.data, src=0, group=self.group)
+
+    def train_step(self, x, labels, step=0):
+        """Forward/backward on this rank's shard.  Every `accum`-th call all-reduces and steps the optimizer.
+        Returns (loss, costh) as device tensors — no host synchronisation."""
+        self._micro += 1
+        last = (self._micro % self.accum == 0)
+        if last:
+            self.reducer.arm()
+        dev_type = "cuda" if x.is_cuda else "cpu"
+        with torch.autocast(dev_type, dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
+            costh, logits = self.net(x, label=labels, step=step)
+        loss = self.criterion(logits.float(), labels)
+        loss.backward()
+        if last:
+            self.reducer.finish()
+            hidden = self.reducer.hide_unused()
+            self.opt.step()
+            self.reducer.restore(hidden)
+            self.reducer.zero()  # grads are views of the flat buffer: one memset instead of zero_grad()
+        return loss.detach(), costh.detach()

@@ -130,9 +130,11 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts
  * cooperating on one (utterance, head) (0 = auto); lds_pad_bytes: extra LDS per
  * workgroup to cap workgroups per CU (0 = none); force_generic: 1 = always take
- * the shape-agnostic kernel.
+ * the shape-agnostic kernel; rows_per_pass: rows a lane keeps in flight per pass
+ * (0 = default for the shape; ignored when no such variant is compiled).
  * ------------------------------------------------------------------------ */
-void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic);
+void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic,
+                           int rows_per_pass);
 /* name of the kernel variant the last dasv_dmha_fwd call on this thread selected */
 const char* dasv_debug_last_variant(void);
 

@@ -1,0 +1,129 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel trainer: the flat-buffer bucketed all-reduce must give
+the same parameters as one process training on the whole batch, with the reference's step semantics
+(global-mean cross-entropy, summed gradient accumulation, parameters that never get a gradient)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class TinyClassifier(nn.Module):
+    """Same call signature as SpeakerClassifier.forward (x, label, step) -> (costh, logits); has parameters that
+    never receive gradients, like b1/b3 in the reference model."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(12, 16)
+        self.unused = nn.BatchNorm1d(16)      # never called
+        self.fc2 = nn.Linear(16, 16)
+        self.bn = nn.BatchNorm1d(16)
+        self.head = nn.Linear(16, 7, bias=False)
+
+    def forward(self, x, label=None, step=0):
+        h = torch.relu(self.fc1(x.mean(dim=1)))
+        h = torch.relu(self.fc2(h))
+        z = self.head(h)
+        return z, 3.0 * z
+
+
+def _data():
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy(rs.standard_normal((2, 8, 5, 12)).astype(np.float32))   # [micro, batch, frames, feat]
+    y = torch.from_numpy(rs.randint(0, 7, size=(2, 8)))
+    return x, y
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, optimizer, accum, bucket_bytes, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from doubleattentionspeakerverification_amd.dist import DataParallelTrainer, init_distributed, shard_batch
+    r, w, dev = init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)          # different init per rank: broadcast_state must fix it
+    net = TinyClassifier().train()
+    net.bn.eval()                           # batch statistics differ between shards by design; keep the maths comparable
+    tr = DataParallelTrainer(net, lr=1e-2, weight_decay=1e-3, optimizer=optimizer, accum=accum, bucket_bytes=bucket_bytes)
+    x, y = _data()
+    for mb in range(accum):
+        lo, hi = shard_batch(x.size(1), rank, world)
+        tr.train_step(x[mb, lo:hi], y[mb, lo:hi], step=0)
+    torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def _single_process(optimizer, accum):
+    torch.manual_seed(100)                  # rank 0's init
+    net = TinyClassifier().train()
+    net.bn.eval()
+    params = list(net.parameters())
+    opt = {"Adam": lambda: torch.optim.Adam(params, lr=1e-2, weight_decay=1e-3),
+           "SGD": lambda: torch.optim.SGD(params, lr=1e-2, weight_decay=1e-3)}[optimizer]()
+    crit = nn.CrossEntropyLoss()
+    x, y = _data()
+    for mb in range(accum):                 # train.py:219-226: grads of micro-batches are summed
+        _, logits = net(x[mb], label=y[mb])
+        crit(logits, y[mb]).backward()
+    opt.step()
+    return net.state_dict()
+
+
+@pytest.mark.parametrize("optimizer,accum,bucket_bytes", [("Adam", 1, 1 << 20), ("SGD", 2, 256), ("Adam", 2, 64)])
+def test_two_rank_gloo_step_matches_single_process(tmp_path, optimizer, accum, bucket_bytes):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, optimizer, accum, bucket_bytes, str(tmp_path)), nprocs=2, join=True)
+    ref = _single_process(optimizer, accum)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    for k in ref:
+        assert torch.equal(r0[k], r1[k]), "ranks diverged on %s" % k
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    # the never-used BatchNorm is untouched: no update, no weight decay (grad is None in the reference too)
+    assert float((r0["unused.weight"] - 1.0).abs().max()) == 0.0
+
+
+def test_flat_buffer_layout_and_buckets():
+    from doubleattentionspeakerverification_amd.dist import FlatGradReducer
+    net = TinyClassifier()
+    red = FlatGradReducer(net.parameters(), bucket_bytes=512)
+    params = [p for p in net.parameters()]
+    # every grad is a view into the flat buffer, 256-byte aligned, last-registered parameter first
+    base = red.flat.data_ptr()
+    offs = [(p.grad.data_ptr() - base) for p in params]
+    assert all(o % 256 == 0 for o in offs)
+    assert offs[-1] == 0 and sorted(offs, reverse=True) == offs
+    covered = sorted((lo, hi) for lo, hi, _ in red.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == red.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert sorted(i for _, _, mem in red.buckets for i in mem) == list(range(len(params)))
+    # single process: arm/finish is a no-op that still leaves summed grads in place
+    red.arm()
+    z, logits = net(torch.randn(4, 3, 12), label=None)
+    logits.sum().backward()
+    red.finish()
+    assert float(net.fc1.weight.grad.abs().sum()) > 0 and float(net.unused.weight.grad.abs().sum()) == 0.0
+    red.zero()
+    assert float(red.flat.abs().sum()) == 0.0
+
+
+def test_shard_batch():
+    from doubleattentionspeakerverification_amd.dist import shard_batch
+    assert [shard_batch(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)

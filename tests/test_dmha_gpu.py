@@ -190,27 +190,27 @@ def test_generic_kernel_matches_vector_kernel():
     x, q, a = _t(rnd(31, 4, 45, 256)), _t(rnd(32, 64, 4, scale=0.3)), _t(rnd(33, 64, 1, scale=0.3))
     out1, al1, _, _ = pool.double_mha(x, q, a)
     assert b"vec<" in lib.dasv_debug_last_variant()
-    lib.dasv_debug_set_tuning(0, 0, 0, 1)
+    lib.dasv_debug_set_tuning(0, 0, 0, 1, 0)
     try:
         out2, al2, _, _ = pool.double_mha(x, q, a)
         assert b"generic" in lib.dasv_debug_last_variant()
     finally:
-        lib.dasv_debug_set_tuning(0, 0, 0, 0)
+        lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
     np.testing.assert_allclose(out1.cpu().numpy(), out2.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(al1.cpu().numpy(), al2.cpu().numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("nw,wpu", [(4, 1), (4, 2), (4, 4), (8, 8), (8, 2), (2, 1), (1, 1)])
-def test_workgroup_shapes_agree(nw, wpu):
+@pytest.mark.parametrize("nw,wpu,rows", [(4, 1, 0), (4, 2, 8), (4, 4, 2), (8, 8, 0), (8, 2, 0), (2, 1, 8), (1, 1, 0), (4, 4, 8)])
+def test_workgroup_shapes_agree(nw, wpu, rows):
     """Every (waves per workgroup, waves per head) split must give the same answer."""
     pool, lib = _pool(), _lib()
     x, q, a = rnd(41, 3, 150, 512), rnd(42, 64, 8, scale=0.3), rnd(43, 64, 1, scale=0.3)
     f = oracle.dmha_closed(x, q, a)
-    lib.dasv_debug_set_tuning(nw, wpu, 0, 0)
+    lib.dasv_debug_set_tuning(nw, wpu, 0, 0, rows)
     try:
         out, al, hw, _ = pool.double_mha(_t(x), _t(q), _t(a))
     finally:
-        lib.dasv_debug_set_tuning(0, 0, 0, 0)
+        lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
     np.testing.assert_allclose(out.cpu().numpy(), f["out"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(al.cpu().numpy(), f["align"], atol=1e-6)
 

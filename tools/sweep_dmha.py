@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--no-att", action="store_true", help="per-head stage only (no in-launch head exchange)")
+    ap.add_argument("--configs", default="", help="semicolon list of nw,wpu,pad,rows tuples to time instead of the default sweep")
     args = ap.parse_args()
     B, T, D, H = (int(v) for v in args.shape.split(","))
     dh = D // H
@@ -72,28 +74,30 @@ def main():
     code = _lib.DTYPE_CODES[str(dt).split(".")[-1]]
     stream = torch.cuda.current_stream().cuda_stream
     ap_ = None if align is None else align.data_ptr()
+    att_p = None if args.no_att else a.data_ptr()
 
     def fwd(i):
-        rc = lib.dasv_dmha_fwd(code, xs[i].data_ptr(), q.data_ptr(), a.data_ptr(), None, None, out.data_ptr(), ap_,
+        rc = lib.dasv_dmha_fwd(code, xs[i].data_ptr(), q.data_ptr(), att_p, None, None, out.data_ptr(), ap_,
                                hw.data_ptr(), ctx.data_ptr(), ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh,
                                T * D, D, stream)
         assert rc == 0, rc
 
-    configs = [(0, 0, 0)]
-    if not args.quick:
-        configs += [(nw, wpu, pad) for nw in (4, 8) for wpu in (1, 2, 4, 8) if wpu <= nw for pad in (0,)]
-        configs += [(8, 8, 48 * 1024), (8, 8, 70 * 1024), (4, 4, 30 * 1024), (4, 4, 45 * 1024)]
-    print("%-28s %10s %10s %9s %9s" % ("config (nw,wpu,ldspad)", "med us", "min us", "GB/s med", "%of 8TB/s"))
-    for nw, wpu, pad in configs:
-        lib.dasv_debug_set_tuning(nw, wpu, pad, 0)
+    configs = [(0, 0, 0, 0)]
+    if args.configs:
+        configs = [tuple(int(v) for v in c.split(",")) for c in args.configs.split(";")]
+    elif not args.quick:
+        configs += [(nw, wpu, 0, r) for nw in (2, 4, 8) for wpu in (1, 2, 4, 8) if wpu <= nw for r in (2, 4, 8)]
+    print("%-28s %10s %10s %9s %9s" % ("config (nw,wpu,ldspad,rows)", "med us", "min us", "GB/s med", "%of 8TB/s"))
+    for nw, wpu, pad, rows in configs:
+        lib.dasv_debug_set_tuning(nw, wpu, pad, 0, rows)
         try:
             med, mn = time_launches(fwd, nbuf, args.iters)
         except AssertionError as e:
-            print("(%d,%d,%d) failed rc=%s" % (nw, wpu, pad, e))
+            print("(%d,%d,%d,%d) failed rc=%s" % (nw, wpu, pad, rows, e))
             continue
         var = lib.dasv_debug_last_variant().decode()
-        print("%-28s %10.2f %10.2f %9.0f %8.1f%%   %s" % ((nw, wpu, pad), med, mn, abytes / med / 1e3, abytes / med / 1e3 / 80.0, var))
-    lib.dasv_debug_set_tuning(0, 0, 0, 0)
+        print("%-30s %10.2f %10.2f %9.0f %8.1f%%   %s" % ((nw, wpu, pad, rows), med, mn, abytes / med / 1e3, abytes / med / 1e3 / 80.0, var))
+    lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
 
     if args.bwd:
         go = torch.randn(B, dh, device=dev, generator=g)
