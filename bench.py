@@ -70,6 +70,29 @@ class PoolTimer:
         return float(np.mean(d)) if d else None
 
 
+def pmc_traffic(workload, dtype):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself; null when no pass was recorded."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return rec.get("%s_%s" % (workload, dtype), {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_embed(params, frames, seconds=12.0):
     import oracle
     from doubleattentionspeakerverification_amd.model import SpeakerClassifier
@@ -166,10 +189,12 @@ def main():
         mod = poolings.DoubleMHA(D, H).to(dev).eval()
         pool_shape = (B, T, D, H)
         with_align = True
+        # The launch is ~14 us, so the serving-style allocation-free launcher is used (one ctypes call per step,
+        # outputs preallocated): the GPU, not Python, is the bottleneck and elapsed/K is the launch time.
+        plan = poolings.DoubleMHAPlan(mod, B, T, dtype=compute_dtype, device=dev, want_align=True)
 
         def step(i):
-            with torch.no_grad():
-                return mod(xs[i % nbuf])[0]
+            return plan(xs[i % nbuf])[0]
         config = {"workload": "DoubleMHA pooling only, B=%d T=%d D=%d heads=%d (BASELINE config 2)" % (B, T, D, H),
                   "global_batch": B * world, "frames": T, "input_buffers_rotated": nbuf, "parallelism": "replicas x%d" % world}
     else:
@@ -205,14 +230,20 @@ def main():
                                   "5994 speakers (BASELINE config 3/4)" % (B, T),
                       "global_batch": B * world, "frames": T, "parallelism": "dp%d (RCCL all-reduce of flat fp32 gradients)" % world}
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        for i in range(count):
+            step(first + i)
+
+    run_steps(0, args.warmup)
     barrier()
     timer.active = True
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    ev0.record()
+    run_steps(args.warmup, args.steps)
+    ev1.record()
     barrier()
+    region_ms = ev0.elapsed_time(ev1)
     elapsed = time.perf_counter() - t0
     timer.active = False
     if dist is not None:
@@ -224,16 +255,19 @@ def main():
         Bp, Tp, Dp, Hp = pool_shape
         abytes = pooling_bytes(Bp, Tp, Dp, Hp, esize, with_align)
         pool_us = timer.mean_us()
+        if args.workload == "pool":   # back-to-back launches on one stream: events around the whole timed region
+            pool_us = region_ms * 1e3 / args.steps
         roofline = None
         if pool_us:
             ach = abytes / pool_us / 1e3  # GB/s
             roofline = {"kernel": "dasv::dmha_fwd_vec (fused DoubleMHA forward)", "bound": "hbm", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic(args.workload, args.dtype),
                         "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(pool_us, 3),
                         "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_debug_last_variant().decode()}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            torch.set_num_threads(os.cpu_count() or 1)
+            torch.set_num_threads(host_cores())
             cpu = cpu_baseline_pool(B, T, 512, 8) if args.workload == "pool" else cpu_baseline_embed(default_params(), T)
         out = {
             "metric": "utterance-embeddings/sec" if args.workload != "train" else "training utterances/sec",

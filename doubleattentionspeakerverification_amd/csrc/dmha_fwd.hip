@@ -67,9 +67,19 @@ struct FwdParams {
 #define DASV_STAMP(p, k) do { } while (0)
 #endif
 
-// LDS carve (floats): [upw][t_pad] scores | [NW][2] (m,l) | [NW][dh] acc | [round_up(H,4)] head scores | flag
-__host__ __device__ inline size_t fwd_lds_floats(int upw, int t_pad, int nw, int H, int dh) {
-    return (size_t)upw * t_pad + (size_t)nw * 2 + (size_t)nw * dh + (size_t)round_up_i(H, 4) + 4;
+// LDS carve (floats).  Stream phase: [upw][t_pad] raw scores | [upw*wpu][2] per-wave (m,l) | [upw*P][dh] per-group
+// partial accumulators (already scaled to their wave's max).  The head stage (last arriver only, after every
+// other use) aliases the same bytes from offset 0: [round_up(H,4)] head weights | [ceil(H/8)][dh] partial
+// outputs.  One flag word at the end.
+__host__ __device__ inline size_t fwd_lds_stream_floats(int upw, int t_pad, int wpu, int P, int dh) {
+    return (size_t)upw * t_pad + (size_t)upw * wpu * 2 + (size_t)upw * P * dh;
+}
+__host__ __device__ inline size_t fwd_lds_head_floats(int H, int dh) {
+    return (size_t)round_up_i(H, 4) + (size_t)((H + 7) / 8) * dh;
+}
+__host__ __device__ inline size_t fwd_lds_floats(int upw, int t_pad, int wpu, int P, int H, int dh) {
+    const size_t a = fwd_lds_stream_floats(upw, t_pad, wpu, P, dh), b = fwd_lds_head_floats(H, dh);
+    return (a > b ? a : b) + 4;
 }
 
 // block -> (utterance, head block): the `arrivals` workgroups of an utterance share blockIdx % 8.
@@ -83,75 +93,95 @@ __device__ __forceinline__ bool block_to_unit(int arrivals, int B, int& b, int& 
 // ---- head stage: executed by the last-arriving workgroup of utterance b ----------------------
 // Every workgroup has already published its context vector c_h (ctx, write-through) and its head score
 // u_h = <c_h, att> (exch_u, write-through).  The last arriver reads the H scores and the H vectors with
-// agent-scope (L1-bypassing) loads only, applies the train-time mask, and writes out / head_w.
-// All threads of the workgroup call this (uniform control flow).  `us` is LDS scratch of >= H floats.
+// agent-scope (L1-bypassing) loads only — ONE round of independent 16-byte loads spread over the whole
+// workgroup — applies the train-time mask, and writes out / head_w.
+// All threads of the workgroup call this (uniform control flow).  `lds` = fwd_lds_head_floats() floats.
 template <bool VEC4>
-__device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* us) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
+__device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* lds) {
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
     const int H = p.H, dh = p.dh, hpad = round_up_i(H, 4);
+    float* ws = lds;            // [H] softmax-over-heads weights
+    float* part = lds + hpad;   // [ceil(H/8)][dh]
     const float* ug = p.exch_u + (size_t)b * hpad;
     const float* cg = p.ctx + (size_t)b * H * dh;
-    for (int hh = tid; hh < H; hh += nthr) {
-        float v = load_agent(ug + hh);
-        if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) v = -INFINITY;
-        us[hh] = v;
-    }
-    constexpr int CH = 8;  // context vectors fetched per round (independent loads in flight per lane)
+    constexpr int CH = 8;  // context vectors per work item (independent loads in flight per lane)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int nvec = dh >> 2, nch = (H + CH - 1) / CH, items = nvec * nch;
+    f4 cv[CH];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cg), 0, H * dh * 4, 0x00020000);
+    auto fetch = [&](int item) {
+        const int chunk = item / nvec, dv = item - chunk * nvec;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int hh = chunk * CH + k;
+            if (hh < H)
+                cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (hh * dh + dv * 4) * 4, 0, 16));
+        }
+    };
     if constexpr (VEC4) {
-        const int nvec = dh >> 2;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cg), 0, H * dh * 4, 0x00020000);
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 cv[CH];
-        const int d4 = tid;
-        if (d4 < nvec) {
+        if (tid < items) fetch(tid);     // the one round of agent-scope vector loads, issued before anything waits
+    }
+    // softmax over heads in wave 0's registers (lane <-> head), DPP reductions, no dependent LDS round trips
+    if (tid < 64) {
+        float mx = -INFINITY;
+        for (int h0 = 0; h0 < H; h0 += 64) {
+            const int hh = h0 + lane;
+            float v = -INFINITY;
+            if (hh < H) {
+                v = load_agent(ug + hh);
+                if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) v = -INFINITY;
+                ws[hh] = v;
+            }
+            mx = fmaxf(mx, group_max<64>(v));
+        }
+        float den = 0.f;
+        for (int h0 = 0; h0 < H; h0 += 64) {
+            const int hh = h0 + lane;
+            const float e = (hh < H) ? fast_exp2((ws[hh] - mx) * kLog2e) : 0.f;   // all masked: NaN, as the reference
+            den += group_sum<64>(e);
+            if (hh < H) ws[hh] = e;
+        }
+        const float inv = 1.0f / den;
+        for (int h0 = 0; h0 < H; h0 += 64) {
+            const int hh = h0 + lane;
+            if (hh < H) {
+                const float wv = ws[hh] * inv;
+                ws[hh] = wv;
+                if (p.head_w != nullptr) p.head_w[(size_t)b * H + hh] = wv;
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (VEC4) {
+        for (int item = tid; item < items; item += nthr) {
+            if (item != tid) fetch(item);
+            const int chunk = item / nvec, dv = item - chunk * nvec;
+            float wk[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) wk[k] = (chunk * CH + k < H) ? ws[chunk * CH + k] : 0.f;
+            f4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < CH; ++k)
-                if (k < H) cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (k * dh + d4 * 4) * 4, 0, 16));
+                if (chunk * CH + k < H) o += wk[k] * cv[k];
+            if (nch == 1) *reinterpret_cast<f4*>(p.out + (size_t)b * dh + dv * 4) = o;
+            else *reinterpret_cast<f4*>(part + (size_t)chunk * dh + dv * 4) = o;
         }
-        __syncthreads();
-        float mx = -INFINITY;
-        for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, us[hh]);
-        float den = 0.f;
-        for (int hh = 0; hh < H; ++hh) den += fast_exp2((us[hh] - mx) * kLog2e);  // all masked: NaN, as the reference
-        const float inv = 1.0f / den;
-        for (int v0 = 0; v0 < nvec; v0 += nthr) {
-            const int dv = v0 + tid;
-            if (dv < nvec) {
-                f4 o = {0.f, 0.f, 0.f, 0.f};
-                for (int h0 = 0; h0 < H; h0 += CH) {
-                    if (v0 != 0 || h0 != 0) {
-#pragma unroll
-                        for (int k = 0; k < CH; ++k)
-                            if (h0 + k < H)
-                                cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((h0 + k) * dh + dv * 4) * 4, 0, 16));
-                    }
-#pragma unroll
-                    for (int k = 0; k < CH; ++k)
-                        if (h0 + k < H) {
-                            const float wk = fast_exp2((us[h0 + k] - mx) * kLog2e) * inv;
-                            o += wk * cv[k];
-                        }
-                }
+        if (nch > 1) {
+            __syncthreads();
+            for (int dv = tid; dv < nvec; dv += nthr) {
+                f4 o = *reinterpret_cast<const f4*>(part + dv * 4);
+#pragma unroll 4
+                for (int c2 = 1; c2 < nch; ++c2) o += *reinterpret_cast<const f4*>(part + (size_t)c2 * dh + dv * 4);
                 *reinterpret_cast<f4*>(p.out + (size_t)b * dh + dv * 4) = o;
             }
         }
-        if (p.head_w != nullptr)
-            for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((us[hh] - mx) * kLog2e) * inv;
     } else {
-        __syncthreads();
-        float mx = -INFINITY;
-        for (int hh = 0; hh < H; ++hh) mx = fmaxf(mx, us[hh]);
-        float den = 0.f;
-        for (int hh = 0; hh < H; ++hh) den += fast_exp2((us[hh] - mx) * kLog2e);
-        const float inv = 1.0f / den;
         for (int d = tid; d < dh; d += nthr) {
             float o = 0.f;
-            for (int hh = 0; hh < H; ++hh) o = fmaf(fast_exp2((us[hh] - mx) * kLog2e) * inv, load_agent(cg + (size_t)hh * dh + d), o);
+            for (int hh = 0; hh < H; ++hh) o = fmaf(ws[hh], load_agent(cg + (size_t)hh * dh + d), o);
             p.out[(size_t)b * dh + d] = o;
         }
-        if (p.head_w != nullptr)
-            for (int hh = tid; hh < H; hh += nthr) p.head_w[(size_t)b * H + hh] = fast_exp2((us[hh] - mx) * kLog2e) * inv;
     }
 }
 
@@ -170,16 +200,16 @@ __device__ __forceinline__ int arrive(const FwdParams& p, int b) {
 
 // Publication, step 2: the workgroup that drew the last ticket runs the head stage.
 template <bool VEC4>
-__device__ __forceinline__ void finish_if_last(const FwdParams& p, int b, int ticket, float* lds_us, int* lds_flag) {
+__device__ __forceinline__ void finish_if_last(const FwdParams& p, int b, int ticket, float* lds_head, int* lds_flag) {
     if (threadIdx.x == 0) {
         const int last = (ticket == p.arrivals - 1);
         if (last) __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave it zeroed
         *lds_flag = last;
     }
-    __syncthreads();
+    __syncthreads();   // also: every wave is past its last use of the stream-phase LDS the head stage aliases
     DASV_STAMP(p, 5);
     if (*lds_flag == 0) return;
-    head_stage<VEC4>(p, b, lds_us);
+    head_stage<VEC4>(p, b, lds_head);
 }
 
 // ---- the streaming kernel ---------------------------------------------------------------------
@@ -189,14 +219,16 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     using E = Elem<XT>;
     constexpr int EPV = E::kPerVec;
     constexpr int GPW = 64 / G;
+    constexpr int DH = G * NI * EPV;
+    constexpr int ND = (DH + 63) / 64;
 
     int b, a;
     if (!block_to_unit(p.arrivals, p.B, b, a)) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int wpu = p.wpu, H = p.H, dh = p.dh, T = p.T;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wpu = p.wpu, upw = p.upw, H = p.H, T = p.T;
     const int uu = w / wpu, wu = w - uu * wpu;
-    const int h = a * p.upw + uu;
+    const int h = a * upw + uu;
     const int c = lane % G, gw = lane / G;
     const int P = wpu * GPW;
     const int phase = wu * GPW + gw;
@@ -204,35 +236,13 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
 
     float* s_lds = smem + (size_t)uu * p.t_pad;
-    float* red_ml = smem + (size_t)p.upw * p.t_pad;
-    float* red_acc = red_ml + 2 * nw;
-    float* stage2 = red_acc + (size_t)nw * dh;
-    int* flag = reinterpret_cast<int*>(stage2 + round_up_i(H, 4));
-
-    // query fragment, pre-scaled so that scores are in the log2 domain
-    float q[NI][EPV];
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)((c + G * j) * EPV + e) * H + h] * p.qscale;
-
-    // head-attention vector for the unit's first wave (used after the stream; fetched now to hide its latency)
-    constexpr int ND = (G * NI * EPV + 63) / 64;
-    float attv[ND];
-#pragma unroll
-    for (int k = 0; k < ND; ++k) attv[k] = (p.att != nullptr && wu == 0 && lane + 64 * k < dh) ? p.att[lane + 64 * k] : 0.f;
+    float* red_ml = smem + (size_t)upw * p.t_pad;             // [upw*wpu][2]
+    float* red_acc = red_ml + (size_t)upw * wpu * 2;          // [upw*P][DH]
+    int* flag = reinterpret_cast<int*>(smem + fwd_lds_floats(upw, p.t_pad, wpu, P, H, DH) - 4);
 
     const char* xrow = static_cast<const char*>(p.x) +
-                       ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
+                       ((size_t)b * p.sb + (size_t)h * DH) * E::kBytes + (size_t)c * 16;
     const size_t row_bytes = (size_t)p.st * E::kBytes;
-
-    float m = -INFINITY, l = 0.f;
-    float acc[NI][EPV];
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) acc[j][e] = 0.f;
-
     const int rows_per_pass = P * R;
     const int npass = (len + rows_per_pass - 1) / rows_per_pass;
 
@@ -250,6 +260,33 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
             }
         }
     };
+
+    // (1) memory ops return in issue order, so: first pass of x, then the query fragment the first pass needs
+    //     (its latency hides behind the x loads already in flight), then the second pass of x, then the
+    //     head-attention vector (needed only after the stream)
+    DASV_STAMP(p, 0);
+    uint4 bufA[R][NI], bufB[R][NI];
+    if (npass > 0) load_pass(bufA, 0);
+    float q[NI][EPV];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)((c + G * j) * EPV + e) * H + h];
+    if (npass > 1) load_pass(bufB, 1);
+    float attv[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) attv[k] = (p.att != nullptr && wu == 0 && lane + 64 * k < DH) ? p.att[lane + 64 * k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) q[j][e] *= p.qscale;   // pre-scaled: scores come out in the log2 domain
+
+    float m = -INFINITY, l = 0.f;
+    float acc[NI][EPV];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[j][e] = 0.f;
 
     auto compute_pass = [&](const uint4 (&buf)[R][NI], int pass) {
         float s[R];
@@ -293,63 +330,84 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         m = m_new;
     };
 
-    DASV_STAMP(p, 0);
-    uint4 bufA[R][NI], bufB[R][NI];
-    if (npass > 0) load_pass(bufA, 0);
+    // (3) the stream: two passes always in flight
     for (int pass = 0; pass < npass; pass += 2) {
-        if (pass + 1 < npass) load_pass(bufB, pass + 1);
         compute_pass(bufA, pass);
         if (pass == 0) DASV_STAMP(p, 1);
+        if (pass + 2 < npass) load_pass(bufA, pass + 2);
         if (pass + 1 < npass) {
-            if (pass + 2 < npass) load_pass(bufA, pass + 2);
             compute_pass(bufB, pass + 1);
+            if (pass + 3 < npass) load_pass(bufB, pass + 3);
         }
     }
     DASV_STAMP(p, 2);
+#ifdef DASV_STAMPS
+    if (lane == 0 && p.stamps != nullptr)
+        p.stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 8 + w] = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    // merge the groups of this wave (xor butterflies across group boundaries)
+    // (4) wave-level (max, sum) by xor butterflies over the groups (2 values only); every group rescales its
+    //     accumulator to the wave's max and parks it in its own LDS slot
+    {
+        float mw = m;
 #pragma unroll
-    for (int off = G; off < 64; off <<= 1) {
-        const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
-        const float mn = fmaxf(m, mo);
-        const float mu = (mn == -INFINITY) ? 0.f : mn;
-        const float ca = fast_exp2(m - mu), cb = fast_exp2(mo - mu);
-        l = l * ca + lo * cb;
+        for (int off = G; off < 64; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off));
+        const float mwu = (mw == -INFINITY) ? 0.f : mw;
+        const float sc = fast_exp2(m - mwu);
+        float lw = l * sc;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) acc[j][e] = acc[j][e] * ca + __shfl_xor(acc[j][e], off) * cb;
-        m = mn;
-    }
-    if (lane < G) {
-        if (lane == 0) { red_ml[2 * w] = m; red_ml[2 * w + 1] = l; }
+        for (int off = G; off < 64; off <<= 1) lw += __shfl_xor(lw, off);
+        if (lane == 0) { red_ml[2 * w] = mw; red_ml[2 * w + 1] = lw; }
+        float* ra = red_acc + (size_t)(uu * P + phase) * DH;
+        typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) red_acc[(size_t)w * dh + (c + G * j) * EPV + e] = acc[j][e];
+            for (int e = 0; e < EPV; e += 4)
+                *reinterpret_cast<f4*>(ra + (c + G * j) * EPV + e) =
+                    f4{acc[j][e] * sc, acc[j][e + 1] * sc, acc[j][e + 2] * sc, acc[j][e + 3] * sc};
     }
     __syncthreads();
 
-    // finish the unit: (M, L) by every thread; context vector + head score by the unit's first wave
-    const int w0 = uu * wpu;
+    // (5) finish the unit: (M, L) by every thread (<= 8 independent LDS reads); context vector + head score by
+    //     the unit's first wave (P independent LDS reads per feature)
+    const float* uml = red_ml + (size_t)uu * wpu * 2;
+    float mwv[8], lwv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mwv[k] = (k < wpu) ? uml[2 * k] : -INFINITY;
+        lwv[k] = (k < wpu) ? uml[2 * k + 1] : 0.f;
+    }
     float M = -INFINITY;
-    for (int k = 0; k < wpu; ++k) M = fmaxf(M, red_ml[2 * (w0 + k)]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) M = fmaxf(M, mwv[k]);
     const float Mu = (M == -INFINITY) ? 0.f : M;
+    float fw[8];
     float L = 0.f;
-    for (int k = 0; k < wpu; ++k) L += red_ml[2 * (w0 + k) + 1] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { fw[k] = fast_exp2(mwv[k] - Mu); L = fmaf(lwv[k], fw[k], L); }
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
     if (wu == 0) {
-        float* cg = p.ctx + ((size_t)b * H + h) * dh;
+        float* cg = p.ctx + ((size_t)b * H + h) * DH;
+        const float* ua = red_acc + (size_t)uu * P * DH;
         float upart = 0.f;
 #pragma unroll
         for (int kd = 0; kd < ND; ++kd) {
             const int d = lane + 64 * kd;
-            if (d < dh) {
+            if (d < DH) {
                 float v = 0.f;
-                for (int k = 0; k < wpu; ++k) v += red_acc[(size_t)(w0 + k) * dh + d] * fast_exp2(red_ml[2 * (w0 + k)] - Mu);
-                v *= invL;
-                store_agent(cg + d, v);
-                upart = fmaf(v, attv[kd], upart);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k < wpu) {
+                        float sg = 0.f;
+#pragma unroll
+                        for (int g2 = 0; g2 < GPW; ++g2) sg += ua[(size_t)(k * GPW + g2) * DH + d];
+                        v = fmaf(sg, fw[k], v);
+                    }
+                }
+                const float cv = v * invL;
+                store_agent(cg + d, cv);
+                upart = fmaf(cv, attv[kd], upart);
             }
         }
         if (p.att != nullptr) {
@@ -370,12 +428,18 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         for (int t = tu; t < T; t += nthr_u) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
     }
     if (p.att == nullptr) return;
-    finish_if_last<true>(p, b, ticket, stage2, flag);
+    finish_if_last<true>(p, b, ticket, smem, flag);
     DASV_STAMP(p, 6);
 }
 
 // ---- shape-agnostic kernel: any dh, any alignment, any stride ---------------------------------
 // One 256-thread workgroup per unit; lane <-> frame for the scores, lane <-> feature for the sums.
+// LDS: [t_pad] scores | [16] reductions | [dh] scaled query   (head stage aliases from 0) | flag at the end
+__host__ __device__ inline size_t fwd_lds_generic_floats(int t_pad, int H, int dh) {
+    const size_t a = (size_t)t_pad + 16 + dh, b = fwd_lds_head_floats(H, dh);
+    return (a > b ? a : b) + 4;
+}
+
 template <typename XT>
 __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -388,10 +452,9 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
 
     float* s_lds = smem;                       // [t_pad]
-    float* red = smem + p.t_pad;               // [2*nw]
-    float* qs = red + 2 * nw;                  // [dh] (lives in the red_acc slot: nw*dh >= dh)
-    float* stage2 = qs + (size_t)nw * dh;
-    int* flag = reinterpret_cast<int*>(stage2 + round_up_i(H, 4));
+    float* red = smem + p.t_pad;               // [16]
+    float* qs = red + 16;                      // [dh]
+    int* flag = reinterpret_cast<int*>(smem + fwd_lds_generic_floats(p.t_pad, H, dh) - 4);
 
     for (int d = tid; d < dh; d += nthr) qs[d] = p.query[(size_t)d * H + h] * p.qscale;
     __syncthreads();
@@ -412,10 +475,10 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     float lloc = 0.f;
     for (int t = tid; t < len; t += nthr) lloc += fast_exp2(s_lds[t] - Mu);
     lloc = group_sum<64>(lloc);
-    if (lane == 0) red[nw + w] = lloc;
+    if (lane == 0) red[4 + w] = lloc;
     __syncthreads();
     float L = 0.f;
-    for (int k = 0; k < nw; ++k) L += red[nw + k];
+    for (int k = 0; k < nw; ++k) L += red[4 + k];
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
     float* cg = p.ctx + ((size_t)b * H + h) * dh;
     float upart = 0.f;
@@ -428,12 +491,11 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     }
     if (p.att != nullptr) {   // head score <c_h, att>: waves -> LDS -> thread 0
         upart = group_sum<64>(upart);
-        __syncthreads();      // everyone is done with red[] from the sum pass
-        if (lane == 0) red[w] = upart;
+        if (lane == 0) red[8 + w] = upart;
         __syncthreads();
         if (tid == 0) {
             float u = 0.f;
-            for (int k = 0; k < nw; ++k) u += red[k];
+            for (int k = 0; k < nw; ++k) u += red[8 + k];
             store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, u);
         }
     }
@@ -448,8 +510,8 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
         for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
     }
     if (p.att == nullptr) return;
-    if ((dh & 3) == 0) finish_if_last<true>(p, b, ticket, stage2, flag);
-    else finish_if_last<false>(p, b, ticket, stage2, flag);
+    if ((dh & 3) == 0) finish_if_last<true>(p, b, ticket, smem, flag);
+    else finish_if_last<false>(p, b, ticket, smem, flag);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -549,7 +611,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
             while (upw > 1 && (long long)groups8 * (H / upw) < 256) upw = largest_divisor_leq(H, upw - 1);
         nw = upw * wpu;
         p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
-        const size_t lds = fwd_lds_floats(upw, p.t_pad, nw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
+        const size_t lds = fwd_lds_floats(upw, p.t_pad, wpu, wpu * gpw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
         if (lds <= 160 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
             hipError_t err = hipSuccess;
@@ -565,7 +627,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     }
     // shape-agnostic path
     p.wpu = 4; p.upw = 1; p.arrivals = H;
-    const size_t lds = fwd_lds_floats(1, p.t_pad, 4, H, dh) * sizeof(float);
+    const size_t lds = fwd_lds_generic_floats(p.t_pad, H, dh) * sizeof(float);
     if (lds > 160 * 1024) return DASV_E_SHAPE;
     dim3 grid((unsigned)(groups8 * H)), block(256);
     hipLaunchKernelGGL((dmha_fwd_generic<XT>), grid, block, lds, stream, p);

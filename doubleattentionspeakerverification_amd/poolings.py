@@ -33,7 +33,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["new_parameter", "Attention", "HeadAttention", "innerKeyValueAttention",
-           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention"]
+           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention", "DoubleMHAPlan"]
 
 
 def new_parameter(*size):
@@ -188,6 +188,44 @@ def multi_head_attention(x, query, lengths=None, want_align=True):
     _require_gpu(x, "multi_head_attention")
     ctx, align, _, _ = _PoolFn.apply(x, query, None, None, lengths, want_align)
     return ctx, (align if want_align else None)
+
+
+class DoubleMHAPlan:
+    """Allocation-free inference launcher for a fixed [B,T,D] shape (serving loops, hipGraph capture).
+
+    Outputs, saved statistics and the workspace are allocated once; every call is exactly one
+    dasv_dmha_fwd launch on the current stream and returns the SAME output tensors (consume or copy them
+    before the next call).  No autograd."""
+
+    def __init__(self, module, batch, frames, dtype=torch.float32, device=None, want_align=True):
+        lib = _lib.load()
+        q = module.utteranceAttention.query
+        device = torch.device(device) if device is not None else q.device
+        dh, H = q.shape
+        f32 = dict(dtype=torch.float32, device=device)
+        self.B, self.T, self.H, self.dh, self.D = batch, frames, H, dh, dh * H
+        self.dtype, self.device = dtype, device
+        self.query = q.detach().to(**f32).contiguous()
+        self.att = module.headsAttention.att.detach().to(**f32).contiguous().view(-1)
+        self.out = torch.empty(batch, dh, **f32)
+        self.align = torch.empty(batch, frames, H, **f32) if want_align else None
+        self.head_w = torch.empty(batch, H, **f32)
+        self.ctx = torch.empty(batch, H, dh, **f32)
+        self.ml = torch.empty(batch, H, 2, **f32)
+        self.ws = torch.zeros(max(4096, lib.dasv_dmha_workspace_bytes(batch, frames, H, dh)), dtype=torch.uint8, device=device)
+        self._fn = lib.dasv_dmha_fwd
+        self._code = _lib.DTYPE_CODES[str(dtype).split(".")[-1]]
+        self._tail = (self.query.data_ptr(), self.att.data_ptr(), None, None, self.out.data_ptr(), _ptr(self.align),
+                      self.head_w.data_ptr(), self.ctx.data_ptr(), self.ml.data_ptr(), self.ws.data_ptr(),
+                      self.ws.numel(), batch, frames, H, dh)
+
+    def __call__(self, x):
+        if x.shape != (self.B, self.T, self.D) or x.dtype != self.dtype or x.device != self.device or x.stride(2) != 1:
+            raise RuntimeError("DoubleMHAPlan was built for a %s %s tensor on %s" % ((self.B, self.T, self.D), self.dtype, self.device))
+        rc = self._fn(self._code, x.data_ptr(), *self._tail, x.stride(0), x.stride(1), _stream_ptr(self.device))
+        if rc != 0:
+            _lib.check(rc, "dasv_dmha_fwd")
+        return self.out, self.align
 
 
 def _like_input(t, x):

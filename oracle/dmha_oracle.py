@@ -34,7 +34,7 @@ __all__ = [
     "mha_closed", "dmha_closed", "dmha_backward_closed", "attention_pool_closed",
     "head_keep_from_torch_rng", "vgg_output_dim", "vgg_out_frames", "vgg_forward",
     "embedding_forward", "classifier_forward", "amsoftmax_forward", "annealed_factor",
-    "cosine_score", "far_frr", "eer_from_scores",
+    "cosine_score", "far_frr", "eer_from_scores", "dmha_c",
 ]
 
 
@@ -251,3 +251,32 @@ def eer_from_scores(clients, impostors):
         return 50.0
     i = int(idx[0])
     return round((far[i] + frr[i]) / 2, 4)
+
+
+# --------------------------------------------------------------------------
+# plain-C restatement (oracle/dmha_oracle.c), loaded through ctypes
+# --------------------------------------------------------------------------
+def dmha_c(x, query, att, head_keep=None):
+    """Run oracle/dmha_oracle.c (build with `make -C oracle`).  Returns the same dict keys as dmha_closed."""
+    import ctypes
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = ctypes.CDLL(os.path.join(here, "libdmha_oracle_c.so"))
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    a = np.ascontiguousarray(att, dtype=np.float32).reshape(-1)
+    B, T, D = x.shape
+    dh, H = q.shape
+    out = np.empty((B, dh), np.float32)
+    align = np.empty((B, T, H), np.float32)
+    head_w = np.empty((B, H), np.float32)
+    ctx = np.empty((B, H, dh), np.float32)
+    keep = None if head_keep is None else np.ascontiguousarray(head_keep, dtype=np.uint8)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib.dmha_oracle_forward(x.ctypes.data_as(fp), q.ctypes.data_as(fp), a.ctypes.data_as(fp),
+                                 None if keep is None else keep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                 out.ctypes.data_as(fp), align.ctypes.data_as(fp), head_w.ctypes.data_as(fp),
+                                 ctx.ctypes.data_as(fp), B, T, H, dh)
+    if rc != 0:
+        raise MemoryError("dmha_oracle_forward")
+    return dict(out=out, align=align, head_w=head_w, ctx=ctx)

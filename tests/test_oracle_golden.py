@@ -185,3 +185,29 @@ def test_g6_scoring_helpers():
         assert oracle.far_frr(cl, t, "FRR") == frr
     cos = oracle.cosine_score(torch.from_numpy(g["cos_e1"]), torch.from_numpy(g["cos_e2"]))
     np.testing.assert_allclose(cos.numpy(), g["cos"], atol=1e-7)
+
+
+# ------------------------------------------------------------------ plain-C restatement
+@pytest.fixture(scope="module")
+def c_oracle():
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")])
+    return oracle.dmha_c
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_c_restatement_matches_reference_vectors(c_oracle, i):
+    g = load_golden("g1_pooling_eval")
+    f = c_oracle(_x(g, i), g["c%d_query" % i], g["c%d_att" % i])
+    np.testing.assert_allclose(f["out"], g["c%d_out" % i], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(f["align"], g["c%d_align" % i], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f["head_w"][..., None], g["c%d_head_w" % i], rtol=0, atol=1e-6)
+
+
+def test_c_restatement_masked_heads(c_oracle):
+    g = load_golden("g2_pooling_train")
+    for i in range(int(g["n"])):
+        f = c_oracle(g["c%d_x" % i], g["c%d_query" % i], g["c%d_att" % i], g["c%d_keep" % i])
+        np.testing.assert_allclose(f["out"], g["c%d_out" % i], atol=2e-6)
+        np.testing.assert_allclose(f["align"], g["c%d_align" % i], atol=1e-6)

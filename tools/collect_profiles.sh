@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace summaries and PMC traffic passes for bench.py.
+# Raw CSVs land under gpurun_out/prof_$TAG/; tools/summarize_profiles.py turns them into profiles/$TAG_*.
+set -o pipefail
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+POOL="python3 bench.py --workload pool --steps 400 --warmup 40 --no-cpu-baseline"
+EMBED="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+echo "== kernel trace: pool"   && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pool_trace  -- $POOL  > $OUT/pool_trace.log 2>&1  || tail -5 $OUT/pool_trace.log
+echo "== kernel trace: embed"  && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed_trace -- $EMBED > $OUT/embed_trace.log 2>&1 || tail -5 $OUT/embed_trace.log
+echo "== pmc FETCH_SIZE: pool" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pool_fetch -- $POOL > $OUT/pool_fetch.log 2>&1 || tail -5 $OUT/pool_fetch.log
+echo "== pmc WRITE_SIZE: pool" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pool_write -- $POOL > $OUT/pool_write.log 2>&1 || tail -5 $OUT/pool_write.log
+echo "== pmc FETCH_SIZE: embed" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/embed_fetch -- $EMBED > $OUT/embed_fetch.log 2>&1 || tail -5 $OUT/embed_fetch.log
+echo "== pmc WRITE_SIZE: embed" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/embed_write -- $EMBED > $OUT/embed_write.log 2>&1 || tail -5 $OUT/embed_write.log
+# keep only what the summary needs (the kernel_trace of the embed run is large)
+find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT
+grep -h '"metric"' $OUT/*.log | cut -c1-400

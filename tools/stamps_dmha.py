@@ -55,9 +55,10 @@ def main():
     ctx, ml = torch.empty(B, H, dh, device=dev), torch.empty(B, H, 2, device=dev)
     ws = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
     nwg_max = 8 * ((B + 7) // 8) * H
-    stamps = torch.zeros(nwg_max, 8, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(2 * nwg_max, 8, dtype=torch.int64, device=dev)  # [grid][8] phase stamps, then [grid][8] per-wave loop-done
     tn = [int(v) for v in args.tuning.split(",")]
     lib.dasv_debug_set_tuning(tn[0], tn[1], tn[2], 0, tn[3])
+    GRID = [0]
     stream = torch.cuda.current_stream().cuda_stream
 
     def launch(i, st):
@@ -66,20 +67,30 @@ def main():
                                out.data_ptr(), None if args.no_align else align.data_ptr(), hw.data_ptr(), ctx.data_ptr(),
                                ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh, T * D, D, stream)
         assert rc == 0, rc
+        import re
+        mm = re.search(r"upw=(\d+)", lib.dasv_debug_last_variant().decode())
+        GRID[0] = 8 * ((B + 7) // 8) * (H // int(mm.group(1))) if mm else nwg_max
     for i in range(20):
         launch(i, None)
     torch.cuda.synchronize()
     names = ["start", "pass0 done", "loop done", "unit done", "drained+barrier", "ticket known", "head stage done"]
-    agg, ivals = [], []
+    agg, ivals, skew = [], [], []
     for rep in range(7):
         stamps.zero_()
         for i in range(8):          # keep the chip in steady state, stamp the last launch only
             launch(rep * 8 + i, None)
         launch(rep * 8 + 8, stamps.data_ptr())
         torch.cuda.synchronize()
-        s = stamps.cpu().numpy().astype(np.float64)
+        sall = stamps.cpu().numpy().astype(np.float64)
+        nblk = GRID[0]
+        s = sall[:nblk]
+        wv = sall[nblk:2 * nblk]
         used = s[:, 0] > 0
+        wv = wv[used]
         s = s[used]
+        wmax = wv.max(axis=1)
+        wmin = np.where(wv > 0, wv, np.inf).min(axis=1)
+        skew.append((np.median(wmax - wmin) * 0.01, np.median(wmax - s[:, 2]) * 0.01, np.median(s[:, 3] - wmax) * 0.01))
         t0 = s[:, 0].min()
         rows = []
         for k in range(7):
@@ -103,6 +114,8 @@ def main():
     for k, nm in enumerate(names):
         n = agg[0, k, 3]
         print("%-18s %8.2f %8.2f %8.2f %6d" % (nm, np.median(agg[:, k, 0]), np.median(agg[:, k, 1]), np.median(agg[:, k, 2]), 0 if np.isnan(n) else int(n)))
+    sk = np.median(np.array(skew), axis=0)
+    print("per-wave loop-done: median spread within a workgroup %.2f us; slowest wave after wave 0: %.2f us; slowest wave -> unit done: %.2f us" % tuple(sk))
     ivals = np.array(ivals, dtype=np.float64)
     print("per-workgroup intervals (us): p10 / median / p90 / max / n")
     for k in range(6):

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into profiles/:
+   <tag>_<run>_kernel_stats.csv  top rows of rocprofv3 --kernel-trace --stats
+   <tag>_summary.md              the fused kernel's average duration, PMC traffic, roofline fractions
+   pmc_traffic.json              HBM bytes per launch (FETCH_SIZE doubled on gfx950 + WRITE_SIZE, KiB -> bytes)"""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+KERNEL = "dasv::dmha_fwd_vec"
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+def stats(run):
+    path = one("%s_trace/*/*kernel_stats.csv" % run)
+    rows = list(csv.DictReader(open(path)))
+    keep = [r for r in rows if KERNEL in r["Name"]] + [r for r in rows if KERNEL not in r["Name"]][:12]
+    with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, run)), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in keep:
+            w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    k = [r for r in rows if KERNEL in r["Name"]]
+    return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3) for r in k}
+
+
+def pmc(run, counter):
+    path = one("%s_%s/*/*counter_collection.csv" % (run, "fetch" if counter == "FETCH_SIZE" else "write"))
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v[2:]) / max(1, len(v[2:])) if len(v) > 2 else sum(v) / len(v) for k, v in vals.items()}
+
+
+def bench_line(run):
+    for line in open(os.path.join(src, "%s_trace.log" % run)):
+        if line.startswith('{"metric"'):
+            return json.loads(line)
+    return None
+
+
+traffic, md = {}, ["# rocprofv3 summary, round tag `%s`\n\n" % tag,
+                   "Commands: `tools/collect_profiles.sh %s` (kernel-trace + stats pass, then separate `--pmc FETCH_SIZE` and "
+                   "`--pmc WRITE_SIZE` passes) around `python3 bench.py --workload pool ...` and `python3 bench.py ...`.\n\n" % tag,
+                   "FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads, MI355X_MICROARCH.md "
+                   "section HBM); both counters are KiB.\n"]
+alg = {"pool": 39954688, "embed": 24965760}
+for run in ("pool", "embed"):
+    st = stats(run)
+    fe, wr = pmc(run, "FETCH_SIZE"), pmc(run, "WRITE_SIZE")
+    bl = bench_line(run)
+    md.append("\n## `%s` workload\n\n" % run)
+    for name, (calls, avg, mn) in st.items():
+        f = fe.get(name, float("nan")) * 1024 * 2
+        w = wr.get(name, float("nan")) * 1024
+        hbm = f + w
+        traffic["%s_fp32" % run] = {"kernel": name, "fetch_bytes_x2": f, "write_bytes": w, "hbm_bytes_per_launch": int(hbm),
+                                    "avg_kernel_us": avg}
+        md.append("* kernel `%s`: %d calls, **average %.2f us** (min %.2f us)\n" % (name, calls, avg, mn))
+        md.append("* PMC per launch: FETCH_SIZE x2 = %.2f MB, WRITE_SIZE = %.2f MB -> HBM traffic %.2f MB vs algorithmic %.2f MB (x%.3f)\n"
+                  % (f / 1e6, w / 1e6, hbm / 1e6, alg[run] / 1e6, hbm / alg[run]))
+        md.append("* algorithmic bytes / kernel time = %.0f GB/s = %.1f %% of 8 TB/s (spec), %.1f %% of 6.29 TB/s (measured copy peak)\n"
+                  % (alg[run] / avg / 1e3, alg[run] / avg / 1e3 / 80, alg[run] / avg / 1e3 / 62.9))
+    if bl:
+        md.append("* bench.py under the profiler: value %.1f %s, roofline avg_launch_us %.2f (events; includes inter-launch gaps)\n"
+                  % (bl["value"], bl["unit"], bl["roofline"]["avg_launch_us"]))
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+open(os.path.join(dst, "%s_summary.md" % tag), "w").write("".join(md))
+print("".join(md))
