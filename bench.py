@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--conv", default="split", choices=["split", "bf16", "torch"],
+                    help="front-end convolutions: hand-written MFMA implicit GEMM with split-bf16 operands (fp32-grade, "
+                         "default) or bf16 operands, or PyTorch-ROCm/MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -201,6 +204,7 @@ def main():
         params = default_params()
         torch.manual_seed(1234)
         net = SpeakerClassifier(params, dev).to(dev)
+        net.front_end.conv_mode = args.conv
         x = torch.from_numpy((2.0 * rs.standard_normal((B, T, 80))).astype(np.float32))
         x = (x - x.mean(dim=1, keepdim=True)).to(dev)  # CMN, as featureExtractor.py:25-26
         Tp = T
@@ -217,7 +221,11 @@ def main():
                     return net.getEmbedding(x)
             config = {"workload": "SpeakerClassifier.getEmbedding, VGG4L/1024 + DoubleMHA(32 heads) + fc, emb 400, "
                                   "input [%d,%d,80] per GPU (reference default config, train.py:263-291)" % (B, T),
-                      "global_batch": B * world, "frames": T, "parallelism": "replicas x%d (no data exchange)" % world}
+                      "global_batch": B * world, "frames": T, "parallelism": "replicas x%d (no data exchange)" % world,
+                      "conv": {"split": "hand-written MFMA implicit GEMM, fp32 operands split into bf16 hi+lo (3 MFMAs per "
+                                        "product, fp32 accumulate; ~5e-6 relative error vs fp32 conv)",
+                               "bf16": "hand-written MFMA implicit GEMM, bf16 operands", "torch": "PyTorch-ROCm / MIOpen"}[args.conv]
+                              if compute_dtype == torch.float32 else "PyTorch-ROCm / MIOpen under bf16 autocast"}
         else:
             from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
             net.train()

@@ -8,14 +8,21 @@ Each block is [conv3x3 pad1 + ReLU] x2 followed by a 2x2 stride-2 ceil-mode max-
 (CNNs.py:49-50 / 88-89).  Parameter names (conv11 ... conv42) match the reference so its
 checkpoints load with strict=True.
 
-Round-1 status: the convolutions run through PyTorch-ROCm (MIOpen) in channels_last
-memory format; hand-written MFMA implicit-GEMM kernels are the "next" row of SURVEY 8(f).
+Convolutions: the wide layers (Cin % 64 == 0, Cout % 128 == 0 — everything but conv11 at the reference's
+kernel sizes) run on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU` of csrc/conv3x3.hip on fp32
+NHWC activations; `conv_mode`:
+  "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
+  "bf16"   operands rounded to bf16 (one MFMA per product)
+  "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs under autocast and for narrow layers)
+conv11 (Cin = 1), the 2x2 ceil-mode max-pools and the final transpose are PyTorch-ROCm device ops.
 """
 import math
 
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+from . import conv as _hipconv
 
 __all__ = ["getVGG3LOutputDimension", "getVGG4LOutputDimension", "VGG3L", "VGG4L"]
 
@@ -48,6 +55,20 @@ class _VGG(nn.Module):
             setattr(self, "conv%d2" % blk, nn.Conv2d(cout, cout, 3, stride=1, padding=1))
             cin = cout
         self.channels_last = True
+        self.conv_mode = "split"
+        self._packed = {}
+
+    def _conv_relu(self, name, h):
+        conv = getattr(self, name)
+        use_hip = (self.conv_mode != "torch" and h.is_cuda and h.dtype == torch.float32
+                   and not torch.is_autocast_enabled() and conv.weight.dtype == torch.float32
+                   and _hipconv.supported(conv.in_channels, conv.out_channels))
+        if not use_hip:
+            return F.relu(conv(h))
+        packed = self._packed.get(name)
+        if packed is None:
+            packed = self._packed[name] = _hipconv.PackedConvWeights()
+        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode)
 
     def forward(self, paddedInputTensor):
         B, T, Fdim = paddedInputTensor.shape
@@ -55,8 +76,8 @@ class _VGG(nn.Module):
         if self.channels_last and h.is_cuda:
             h = h.contiguous(memory_format=torch.channels_last)
         for blk in range(1, self.n_blocks + 1):
-            h = F.relu(getattr(self, "conv%d1" % blk)(h))
-            h = F.relu(getattr(self, "conv%d2" % blk)(h))
+            h = self._conv_relu("conv%d1" % blk, h)
+            h = self._conv_relu("conv%d2" % blk, h)
             h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
         return h.permute(0, 2, 1, 3).reshape(B, h.size(2), h.size(1) * h.size(3))

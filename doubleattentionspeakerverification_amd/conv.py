@@ -1,0 +1,87 @@
+"""conv3x3 + bias + ReLU through libdasv_hip.so (csrc/conv3x3.hip): the hand-written MFMA implicit-GEMM that
+replaces `F.relu(self.convXY(x))` of the reference's CNNs.py:38-48 / 72-86 for the wide layers.
+
+Activations stay fp32 in NHWC memory (torch `channels_last` tensors are passed zero-copy).  mode "split" keeps fp32
+accuracy on the bf16 matrix cores (operands split hi + lo, three MFMAs per product); mode "bf16" rounds operands to
+bf16.  Backward (training) goes through ATen's convolution_backward on the saved tensors.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported"]
+
+MODES = {"split": 0, "bf16": 1}
+
+
+def supported(cin, cout):
+    return cin % 64 == 0 and cout % 128 == 0
+
+
+class PackedConvWeights:
+    """bf16 hi/lo planes [Cout][9][Cin] of a Conv2d weight, re-packed when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.hi = self.lo = None
+
+    def get(self, weight):
+        key = (weight.data_ptr(), weight._version, weight.device)
+        if key != self.key:
+            lib = _lib.load()
+            cout, cin = weight.shape[0], weight.shape[1]
+            n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
+            w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
+            if self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
+                self.hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
+                self.lo = torch.empty(n, dtype=torch.uint8, device=weight.device)
+            with torch.cuda.device(weight.device):
+                rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin,
+                                                   torch.cuda.current_stream(weight.device).cuda_stream)
+            _lib.check(rc, "dasv_conv3x3_pack_weights")
+            self.key = key
+        return self.hi, self.lo
+
+
+def _launch(x, hi, lo, bias, cout, mode):
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                             None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout, 1,
+                                             torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_nhwc")
+    return y
+
+
+class _ConvReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, mode):
+        hi, lo = packed.get(weight)
+        y = _launch(x, hi, lo, bias, weight.shape[0], mode)
+        ctx.save_for_backward(x, weight, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = gy * (y > 0)
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        return gx, gw, gb, None, None
+
+
+def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split"):
+    """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last."""
+    if not x.is_cuda:
+        raise RuntimeError("conv3x3_bias_relu runs on the GPU only (libdasv_hip.so); no CPU fallback")
+    if x.dtype != torch.float32 or not supported(weight.shape[1], weight.shape[0]):
+        raise RuntimeError("unsupported conv3x3 shape/dtype for the HIP kernel: %s %s" % (tuple(weight.shape), x.dtype))
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    packed = packed or PackedConvWeights()
+    b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
+    return _ConvReLUFn.apply(x, weight, b, packed, mode)

@@ -541,9 +541,9 @@ static bool dispatch_vec(int G, int NI, int R, const FwdParams& p, dim3 grid, di
 #define DASV_CASE(g, n, r) if (G == g && NI == n && R == r) { err = launch_vec<XT, g, n, r>(p, grid, block, lds, s); return true; }
     DASV_CASE(16, 1, 4) DASV_CASE(16, 1, 2) DASV_CASE(16, 1, 8)
     DASV_CASE(16, 2, 2) DASV_CASE(16, 2, 4) DASV_CASE(16, 3, 2) DASV_CASE(16, 4, 1) DASV_CASE(16, 4, 2)
-    DASV_CASE(16, 5, 1) DASV_CASE(16, 5, 2) DASV_CASE(16, 6, 1) DASV_CASE(16, 7, 1) DASV_CASE(16, 8, 1)
-    DASV_CASE(8, 1, 4) DASV_CASE(8, 1, 8) DASV_CASE(8, 3, 2) DASV_CASE(8, 5, 1) DASV_CASE(8, 5, 2) DASV_CASE(8, 7, 1)
-    DASV_CASE(4, 1, 4) DASV_CASE(4, 1, 8) DASV_CASE(4, 3, 2) DASV_CASE(4, 5, 1) DASV_CASE(4, 5, 2) DASV_CASE(4, 7, 1)
+    DASV_CASE(16, 5, 1) DASV_CASE(16, 5, 2) DASV_CASE(16, 5, 3) DASV_CASE(16, 6, 1) DASV_CASE(16, 7, 1) DASV_CASE(16, 8, 1)
+    DASV_CASE(8, 1, 4) DASV_CASE(8, 1, 8) DASV_CASE(8, 3, 2) DASV_CASE(8, 5, 1) DASV_CASE(8, 5, 2) DASV_CASE(8, 5, 3) DASV_CASE(8, 7, 1)
+    DASV_CASE(4, 1, 4) DASV_CASE(4, 1, 8) DASV_CASE(4, 3, 2) DASV_CASE(4, 5, 1) DASV_CASE(4, 5, 2) DASV_CASE(4, 5, 3) DASV_CASE(4, 7, 1)
 #undef DASV_CASE
     return false;
 }
@@ -607,8 +607,12 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
         if (nw > 8) nw = 8;
         if (nw < wpu) nw = wpu;
         int upw = largest_divisor_leq(H, nw / wpu);
-        if (g_tuning.nw <= 0)
+        if (g_tuning.nw <= 0) {
+            // never fewer workgroups than CUs; and once there are several rounds of workgroups per CU, smaller
+            // workgroups (more of them resident) hide each other's finish latency better
             while (upw > 1 && (long long)groups8 * (H / upw) < 256) upw = largest_divisor_leq(H, upw - 1);
+            while (upw * wpu > 4 && upw > 1 && (long long)groups8 * (H / upw) > 1024) upw = largest_divisor_leq(H, upw - 1);
+        }
         nw = upw * wpu;
         p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
         const size_t lds = fwd_lds_floats(upw, p.t_pad, wpu, wpu * gpw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
@@ -617,7 +621,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
             hipError_t err = hipSuccess;
             bool ok = g_tuning.rows > 0 && dispatch_vec<XT>(G, NI, g_tuning.rows, p, grid, block, lds, stream, err);
             if (ok) R = g_tuning.rows;
-            else ok = dispatch_vec<XT>(G, NI, R, p, grid, block, lds, stream, err);
+            if (!ok) ok = dispatch_vec<XT>(G, NI, R, p, grid, block, lds, stream, err);
             if (ok) {
                 snprintf(g_last_variant, sizeof(g_last_variant), "vec<dtype=%d,G=%d,NI=%d,R=%d> nw=%d wpu=%d upw=%d lds=%zu",
                          XT::kCode, G, NI, R, nw, wpu, upw, lds);

@@ -126,6 +126,24 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
                   int64_t x_stride_b, int64_t x_stride_t, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * conv3x3 (stride 1, pad 1) + bias + ReLU on NHWC fp32 activations, as an implicit GEMM on the matrix cores.
+ * Replaces `F.relu(self.convXY(x))` of CNNs.py:38-48 / 72-86 for layers with Cin % 64 == 0 and
+ * Cout % 128 == 0 (conv12 ... conv42 at the reference's kernel sizes; conv11 has Cin = 1 and stays in torch).
+ *
+ *   dasv_conv3x3_pack_weights: torch-layout weights [Cout,Cin,3,3] fp32 -> two bf16 planes [Cout][9][Cin]
+ *                              (hi = bf16(w), lo = bf16(w - hi)), each dasv_conv3x3_packed_weight_bytes() long.
+ *                              Call again whenever the weights change.
+ *   dasv_conv3x3_bias_relu_nhwc: x [B,H,W,Cin] fp32 -> y [B,H,W,Cout] fp32 (y = relu?(conv(x) + bias)).
+ *       mode 0: split-bf16 operands (x = hi + lo, three MFMAs per product, fp32 accumulate): ~2^-16 relative error
+ *               per product, fp32-grade for this model's 1e-3 embedding bar.
+ *       mode 1: plain bf16 operands (one MFMA per product).
+ * ------------------------------------------------------------------------ */
+size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin);
+int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, dasv_stream_t stream);
+int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts
  * cooperating on one (utterance, head) (0 = auto); lds_pad_bytes: extra LDS per

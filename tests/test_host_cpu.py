@@ -136,3 +136,23 @@ def test_reference_style_checkpoint_loads_under_weights_only_default(tmp_path):
     torch.save({"model": {"w": torch.ones(2)}, "optimizer": {}, "settings": ns, "epoch": 1, "step": 2}, path)
     d = torch.load(path, map_location=torch.device("cpu"))
     assert d["settings"].kernel_size == 16 and d["step"] == 2
+
+
+def test_length_bucketing_and_dealing():
+    from doubleattentionspeakerverification_amd.batching import bucket_by_length, deal_buckets
+    rs = np.random.RandomState(3)
+    lengths = list(rs.randint(150, 801, size=400)) + [300] * 150
+    buckets = bucket_by_length(lengths, max_batch=64, max_frames=64 * 300)
+    seen = sorted(i for b in buckets for i in b)
+    assert seen == list(range(len(lengths)))                      # a partition
+    for b in buckets:
+        assert len({lengths[i] for i in b}) == 1                   # equal lengths only
+        assert len(b) <= 64 and len(b) * lengths[b[0]] <= 64 * 300 or len(b) == 1
+    assert [lengths[b[0]] for b in buckets] == sorted((lengths[b[0]] for b in buckets), reverse=True)
+    parts = deal_buckets(buckets, lengths, 8)
+    loads = [sum(lengths[i] for b in p for i in b) for p in parts]
+    assert sorted(i for p in parts for b in p for i in b) == list(range(len(lengths)))
+    assert (max(loads) - min(loads)) / (sum(loads) / 8) < 0.05    # balanced to a few percent
+    assert deal_buckets(buckets, lengths, 8) == parts               # deterministic
+    with pytest.raises(ValueError):
+        bucket_by_length([10, 0, 3])

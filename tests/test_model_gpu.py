@@ -168,3 +168,70 @@ def test_embedding_example_flow_from_reference_style_checkpoint(tmp_path):
     with torch.no_grad():
         ref = oracle.embedding_forward(torch.from_numpy(feats).unsqueeze(0), sd, 4, 4)
     assert float((emb.cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+def test_variable_length_bucketed_embeddings_equal_one_at_a_time_runs():
+    """BASELINE config 5 semantics: T in [150,800], equal-length buckets == the reference's one-utterance-per-forward
+    scoring (train.py:107-133); also the fp16-autocast path's error is stated."""
+    from doubleattentionspeakerverification_amd.batching import embed_utterances
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    torch.manual_seed(7)
+    net = SpeakerClassifier(_params(ks=32, H=8, emb=32), torch.device(DEV)).to(DEV).eval()
+    rs = np.random.RandomState(11)
+    pool = [150, 151, 299, 300, 800]
+    lengths = [pool[i % 5] for i in range(23)]
+    utts = [torch.from_numpy(rnd(900 + i, n, 80)) for i, n in enumerate(lengths)]
+    got = embed_utterances(net, utts, max_batch=8)
+    assert sorted(got) == list(range(23))
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    worst = 0.0
+    for i in (0, 1, 2, 3, 4, 7, 13, 22):
+        with torch.no_grad():
+            one = net.getEmbedding(utts[i].unsqueeze(0).to(DEV))[0].cpu()
+            ref = oracle.embedding_forward(utts[i].unsqueeze(0), sd, 4, 8)[0]
+        worst = max(worst, float((got[i].cpu() - one).abs().max() / one.abs().max()))
+        assert float((got[i].cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert worst < 1e-5, worst
+    # two ranks own disjoint halves and together cover everything
+    a = embed_utterances(net, utts, max_batch=8, rank=0, world=2)
+    b = embed_utterances(net, utts, max_batch=8, rank=1, world=2)
+    assert set(a) | set(b) == set(range(23)) and not (set(a) & set(b))
+    h = embed_utterances(net, utts, max_batch=8, autocast_dtype=torch.float16)
+    rel16 = max(float((h[i].cpu() - got[i].cpu()).abs().max() / got[i].cpu().abs().max()) for i in range(23))
+    print("fp16-autocast embeddings vs fp32: max rel err %.3e" % rel16)
+    assert rel16 < 2e-2
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 9, 7, 3), (128, 128, 33, 80, 2), (256, 512, 19, 5, 4), (128, 256, 1, 1, 1)])
+def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
+    """Hand-written implicit-GEMM conv (csrc/conv3x3.hip) against a float64 convolution: split mode is fp32-grade
+    (<= 2e-5 of the output scale), bf16 mode is stated (<= 1e-2); includes image borders, M tails and 1x1 maps."""
+    from doubleattentionspeakerverification_amd import conv
+    x = torch.from_numpy(rnd(1, B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    b = torch.from_numpy(rnd(3, cout, scale=0.1)).to(DEV)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))
+    scale = float(ref.abs().max())
+    with torch.no_grad():
+        ys = conv.conv3x3_bias_relu(x, w, b, None, "split").cpu().double()
+        yb = conv.conv3x3_bias_relu(x, w, b, None, "bf16").cpu().double()
+    assert ys.shape == ref.shape
+    assert float((ys - ref).abs().max()) / scale < 2e-5
+    assert float((yb - ref).abs().max()) / scale < 1e-2
+
+
+def test_hip_conv_backward_matches_torch_autograd():
+    from doubleattentionspeakerverification_amd import conv
+    x = torch.from_numpy(rnd(4, 2, 64, 10, 6)).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.from_numpy(rnd(5, 128, 64, 3, 3, scale=0.05)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rnd(6, 128, scale=0.1)).to(DEV).requires_grad_(True)
+    gy = torch.from_numpy(rnd(7, 2, 128, 10, 6)).to(DEV)
+    y = conv.conv3x3_bias_relu(x, w, b, None, "split")
+    (y * gy).sum().backward()
+    g1 = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    yr = torch.relu(torch.nn.functional.conv2d(x, w, b, padding=1))
+    (yr * gy).sum().backward()
+    for a, r in zip(g1, (x.grad, w.grad, b.grad)):
+        np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(r.abs().max()))
