@@ -18,6 +18,8 @@
 #include "dasv_common.hpp"
 #include "../../include/dasv_hip.h"
 
+#include <stdlib.h>
+
 namespace dasv {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -29,11 +31,16 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;   // inputs are finite activations/weights
 }
+// (a, b) -> packed bf16 pairs hi = bf16(v) and lo = bf16(v - hi); plain casts lower to v_cvt_pk_bf16_f32 (RNE)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const uint32_t ha = bf16_rne(a), hb = bf16_rne(b);
-    const float ra = a - __uint_as_float(ha << 16), rb = b - __uint_as_float(hb << 16);
-    hi = ha | (hb << 16);
-    lo = bf16_rne(ra) | (bf16_rne(rb) << 16);
+    const f32x2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    const f32x2_t hf = __builtin_convertvector(h, f32x2_t);
+    const bf16x2_t l = __builtin_convertvector(v - hf, bf16x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
 }
 
 // weights [Cout][Cin][3][3] fp32 (torch) -> hi/lo planes [Cout][9][Cin] bf16
@@ -89,19 +96,22 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
 
     // ---- A staging: thread handles fp32 chunk (16 B = 4 channels) `ach` of rows arow0 + 16*i, i < 8
     const int ach = tid & 15, arow0 = tid >> 4;
-    int apix[8];      // (b*H + h)*W + w of the output pixel, or -1 beyond M
-    int ahw[8];       // h << 16 | w
+    const float* aptr[8];   // &x[pixel][ach*4] of the output pixel (centre tap)
+    unsigned amask[8];      // bit `tap` set: that tap's source pixel is inside the image (0 beyond M)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + arow0 + 16 * i;
+        unsigned mask = 0;
         if (m < p.M) {
-            const int w_ = m % W, t2 = m / W, h_ = t2 % H;
-            apix[i] = m;
-            ahw[i] = (h_ << 16) | w_;
-        } else {
-            apix[i] = -1;
-            ahw[i] = 0;
+            const int w_ = m % W, h_ = (m / W) % H;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
+                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
+            }
         }
+        amask[i] = mask;
+        aptr[i] = p.x + (size_t)(m < p.M ? m : 0) * Cin + ach * 4;
     }
     // ---- B staging: thread handles 16-byte chunk `bch` (8 bf16) of rows brow0 + 32*i, i < 4 (per plane)
     const int bch = tid & 7, brow0 = tid >> 3;
@@ -114,12 +124,11 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
         const int csteps = Cin / CBK;
         const int tap = ks / csteps, c0 = (ks - tap * csteps) * CBK;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long long aoff = (long long)(dy * W + dx) * Cin + c0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int h_ = (ahw[i] >> 16) + dy, w_ = (ahw[i] & 0xffff) + dx;
-            const bool ok = apix[i] >= 0 && (unsigned)h_ < (unsigned)H && (unsigned)w_ < (unsigned)W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(apix[i] + dy * W + dx)) * Cin + c0 + ach * 4);
+            if ((amask[i] >> tap) & 1u) v = *reinterpret_cast<const f32x4*>(aptr[i] + aoff);
             ra[i] = v;
         }
 #pragma unroll
@@ -211,6 +220,175 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Window variant (the fast path for W <= 80): per 64-channel slab the workgroup stages ONE contiguous raster
+// window of the input — its 256 output pixels plus W+1 pixels of halo on each side — and runs all nine taps out
+// of LDS: the A fragment of tap (dy,dx) for output pixel m is simply window row (m - m0) + (W+1) + dy*W + dx, and a
+// 9-bit per-pixel mask zeroes taps that fall outside the image (left/right edge, top/bottom, neighbouring image).
+// Each input element is fetched from HBM/L2, split and written to LDS once per slab instead of once per tap, and the
+// weights of a tap are staged once per 256 pixels.  8 waves (4 x 2), each 64 x 64 outputs.
+// LDS: A_hi | A_lo windows of `wrows` x 128 B, then B_hi | B_lo tiles of 128 x 128 B.
+constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 511) / 512;
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int W = p.W, H = p.H, Cin = p.Cin;
+    const int wrows = WBM + 2 * W + 2;
+    char* Ahi = smem;
+    char* Alo = Ahi + (size_t)wrows * 128;
+    char* Bhi = Alo + (SPLIT ? (size_t)wrows * 128 : 0);
+    char* Blo = Bhi + 16384;
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * p.tiles_per_xcd + idx;
+    if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * WBM, n0 = nt * CBN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // border masks of this lane's four A-fragment pixels
+    unsigned amask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        unsigned mask = 0;
+        if (m < p.M) {
+            const int w_ = m % W, h_ = (m / W) % H;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
+                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
+            }
+        }
+        amask[i] = mask;
+    }
+
+    // A window staging: chunk q = tid + 512*k covers window row q/16, fp32 chunk q%16 (4 channels)
+    const int wchunks = wrows * 16;
+    const long long wbase = (long long)m0 - W - 1;   // global pixel index of window row 0
+    f32x4 ra[WACH];
+    auto load_window = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < WACH; ++k) {
+            const int q = tid + 512 * k;
+            const long long pix = wbase + (q >> 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q < wchunks && pix >= 0 && pix < p.M) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * Cin + c0 + (q & 15) * 4);
+            ra[k] = v;
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int k = 0; k < WACH; ++k) {
+            const int q = tid + 512 * k;
+            if (q < wchunks) {
+                const int row = q >> 4, ach = q & 15;
+                uint32_t h0, l0, h1, l1;
+                split2(ra[k][0], ra[k][1], h0, l0);
+                split2(ra[k][2], ra[k][3], h1, l1);
+                const int o = lds_off(row, ach >> 1) + (ach & 1) * 8;
+                *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
+                if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
+            }
+        }
+    };
+    // B staging: 128 rows x 8 chunks per plane = 1024 chunks; thread handles chunk tid and tid + 512
+    u32x4 rbh[2], rbl[2];
+    auto load_b = [&](int tap, int c0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + 512 * k;
+            const size_t off = ((size_t)(n0 + (q >> 3)) * 9 + tap) * Cin + c0 + (q & 7) * 8;
+            rbh[k] = *reinterpret_cast<const u32x4*>(p.whi + off);
+            if (SPLIT) rbl[k] = *reinterpret_cast<const u32x4*>(p.wlo + off);
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + 512 * k;
+            const int o = lds_off(q >> 3, q & 7);
+            *reinterpret_cast<u32x4*>(Bhi + o) = rbh[k];
+            if (SPLIT) *reinterpret_cast<u32x4*>(Blo + o) = rbl[k];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = Cin / CBK;
+    load_b(0, 0);
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int c0 = sl * CBK;
+        load_window(c0);                      // previous slab's readers are behind the barrier that ended its last tap
+        store_window();
+        for (int tap = 0; tap < 9; ++tap) {
+            store_b();
+            __syncthreads();
+            if (tap < 8) load_b(tap + 1, c0);
+            else if (sl + 1 < nslab) load_b(0, c0 + CBK);
+            const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int slot = kk * 4 + fq;
+                bf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = lds_off(wn * 64 + j * 16 + frow, slot);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + o);
+                    if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Blo + o);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = lds_off(wm * 64 + i * 16 + frow + shift, slot);
+                    const bool ok = (amask[i] >> tap) & 1u;
+                    bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + o);
+                    bf16x8 al;
+                    if (SPLIT) al = *reinterpret_cast<const bf16x8*>(Alo + o);
+                    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                    ah = ok ? ah : zero;
+                    if (SPLIT) al = ok ? al : zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                        if (SPLIT) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (m < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[(size_t)m * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dasv
 
 extern "C" {
@@ -240,13 +418,29 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
     dasv::ConvParams p;
     p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
-    p.mtiles = (p.M + dasv::CBM - 1) / dasv::CBM;
+    hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
+    static int force_tile_kernel = -1;
+    if (force_tile_kernel < 0) force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;
+    if (W <= 80 && !force_tile_kernel) {
+        p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
+        p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
+        const int wrows = dasv::WBM + 2 * W + 2;
+        const size_t lds = (size_t)wrows * 128 * (mode == 0 ? 2 : 1) + 32768;
+        const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(512);
+        const void* fn = mode == 0 ? reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<true>)
+                                   : reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (mode == 0) hipLaunchKernelGGL(dasv::conv3x3_window_kernel<true>, grid, block, lds, s, p);
+        else hipLaunchKernelGGL(dasv::conv3x3_window_kernel<false>, grid, block, lds, s, p);
+        return (int)hipGetLastError();
+    }
+    p.mtiles = (p.M + dasv::CBM - 1) / dasv::CBM;
     const int tiles = p.mtiles * p.ntiles;
     p.tiles_per_xcd = (tiles + 7) / 8;
     const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(256);
     const size_t lds = 65536;
-    hipStream_t s = (hipStream_t)stream;
     if (mode == 0) {
         static bool attr0 = false;
         if (!attr0) {
