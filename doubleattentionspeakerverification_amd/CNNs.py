@@ -14,7 +14,8 @@ NHWC activations; `conv_mode`:
   "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs under autocast and for narrow layers)
-conv11 (Cin = 1), the 2x2 ceil-mode max-pools and the final transpose are PyTorch-ROCm device ops.
+Under torch.no_grad() conv11 (Cin = 1) and the 2x2 ceil-mode max-pools also run on hand-written HIP kernels
+(csrc/frontend_misc.hip, pure HBM streams); when a graph is being recorded they are PyTorch-ROCm device ops.
 """
 import math
 
@@ -70,15 +71,27 @@ class _VGG(nn.Module):
             packed = self._packed[name] = _hipconv.PackedConvWeights()
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode)
 
+    def _hip_inference(self, x):
+        """All-HIP inference path: no autograd graph is being built and the activations are fp32 on the GPU."""
+        c11 = self.conv11
+        return (self.conv_mode != "torch" and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled() and c11.weight.dtype == torch.float32
+                and c11.out_channels % 4 == 0 and 256 % (c11.out_channels // 4) == 0 and c11.out_channels <= 1024)
+
     def forward(self, paddedInputTensor):
         B, T, Fdim = paddedInputTensor.shape
-        h = paddedInputTensor.reshape(B, 1, T, Fdim)
-        if self.channels_last and h.is_cuda:
-            h = h.contiguous(memory_format=torch.channels_last)
+        hip = self._hip_inference(paddedInputTensor)
+        if hip:
+            h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias)
+        else:
+            h = paddedInputTensor.reshape(B, 1, T, Fdim)
+            if self.channels_last and h.is_cuda:
+                h = h.contiguous(memory_format=torch.channels_last)
         for blk in range(1, self.n_blocks + 1):
-            h = self._conv_relu("conv%d1" % blk, h)
+            if not (hip and blk == 1):
+                h = self._conv_relu("conv%d1" % blk, h)
             h = self._conv_relu("conv%d2" % blk, h)
-            h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
+            h = _hipconv.maxpool2x2_ceil(h) if hip else F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
         return h.permute(0, 2, 1, 3).reshape(B, h.size(2), h.size(1) * h.size(3))
 

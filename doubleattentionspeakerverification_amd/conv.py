@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported"]
+__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil"]
 
 MODES = {"split": 0, "bf16": 1}
 
@@ -85,3 +85,32 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split"):
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
     return _ConvReLUFn.apply(x, weight, b, packed, mode)
+
+
+def conv3x3_c1_bias_relu(x, weight, bias):
+    """Inference-only relu(conv2d(x[:,None], weight, bias, padding 1)) for x [B,H,W] fp32; returns [B,Cout,H,W]
+    channels_last (NHWC memory).  One input channel: a pure HBM write stream (csrc/frontend_misc.hip)."""
+    lib = _lib.load()
+    B, H, W = x.shape
+    cout = weight.shape[0]
+    x = x.contiguous()
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_c1_bias_relu_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                None if bias is None else bias.detach().data_ptr(), y.data_ptr(), B, H, W, cout, 1,
+                                                torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_c1_bias_relu_nhwc")
+    return y
+
+
+def maxpool2x2_ceil(x):
+    """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W]."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_maxpool2x2_ceil_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_maxpool2x2_ceil_nhwc")
+    return y

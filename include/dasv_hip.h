@@ -143,6 +143,14 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 
+/* conv3x3 with ONE input channel (+ bias + ReLU): x [B,H,W] fp32 -> y [B,H,W,Cout] NHWC fp32.  Replaces
+ * `F.relu(self.conv11(x))` (CNNs.py:38 / 72); w is the torch weight [Cout,1,3,3].  Cout % 4 == 0, (Cout/4) | 256. */
+int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                                   int Cout, int relu, dasv_stream_t stream);
+/* 2x2 stride-2 ceil-mode max-pool on NHWC fp32: x [B,H,W,C] -> y [B,ceil(H/2),ceil(W/2),C].  Replaces
+ * `F.max_pool2d(x, 2, stride=2, ceil_mode=True)` (CNNs.py:40,44,48 / 74,78,82,86).  C % 4 == 0. */
+int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts

@@ -235,3 +235,18 @@ def test_hip_conv_backward_matches_torch_autograd():
     (yr * gy).sum().backward()
     for a, r in zip(g1, (x.grad, w.grad, b.grad)):
         np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(r.abs().max()))
+
+
+def test_hip_conv11_and_maxpool_match_torch():
+    from doubleattentionspeakerverification_amd import conv
+    x = torch.from_numpy(rnd(21, 3, 37, 80)).to(DEV)
+    w = torch.from_numpy(rnd(22, 128, 1, 3, 3, scale=0.3)).to(DEV)
+    b = torch.from_numpy(rnd(23, 128, scale=0.1)).to(DEV)
+    ref = torch.relu(torch.nn.functional.conv2d(x.unsqueeze(1), w, b, padding=1))
+    y = conv.conv3x3_c1_bias_relu(x, w, b)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for shape in ((2, 128, 37, 80), (3, 64, 19, 5), (1, 16, 1, 1), (2, 32, 10, 3)):
+        t = torch.from_numpy(rnd(24, *shape)).to(DEV).contiguous(memory_format=torch.channels_last)
+        pr = torch.nn.functional.max_pool2d(t, 2, stride=2, ceil_mode=True)
+        pm = conv.maxpool2x2_ceil(t)
+        assert pm.shape == pr.shape and torch.equal(pm, pr)
