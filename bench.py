@@ -13,8 +13,11 @@ For N > 1 the driver launches one rank per GPU (torch.distributed.run); every ra
 (weak scaling, replicas only for embed/pool — the path has no data exchange — and one gradient all-reduce
 per step for train).  Rank 0 prints ONE JSON line.
 
-`roofline` describes the fused DoubleMHA kernel (HBM-bound): algorithmic bytes per launch over its
-average duration measured with events on the launch stream inside the timed region.  `cpu_baseline` times the
+`roofline` describes the kernel that dominates the step: for `embed`/`train` the hand-written conv3x3 implicit GEMM
+(MFMA-bound: algorithmic FLOPs of its launches over their event-timed duration, against the dense bf16 MFMA peak;
+split-bf16 operands execute 3 MFMA FLOPs per algorithmic FLOP, reported separately), for `pool` the fused DoubleMHA
+kernel (HBM-bound: algorithmic bytes per launch).  `roofline_pooling` always describes the DoubleMHA
+kernel.  `cpu_baseline` times the
 op-sequence-faithful CPU restatement (oracle/, kind "port") on a bounded sample on rank 0 at N=1.
 """
 import argparse
@@ -31,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the conv's MFMAs are bf16, fp32 accumulate)
 
 
 def default_params():
@@ -68,6 +72,35 @@ class PoolTimer:
     def mean_us(self):
         d = [s.elapsed_time(e) * 1e3 for s, e in self.pairs]
         return float(np.mean(d)) if d else None
+
+
+class ConvTimer:
+    """Events around every hand-written conv3x3 launch inside the timed region (launch stream), with the
+    algorithmic FLOPs of each launch (2*9*Cin*Cout*B*H*W)."""
+
+    def __init__(self, convmod):
+        self.rec = []
+        self.active = False
+        inner = convmod._launch
+
+        def timed(x, hi, lo, bias, cout, mode):
+            if not self.active:
+                return inner(x, hi, lo, bias, cout, mode)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(torch.cuda.current_stream(x.device))
+            y = inner(x, hi, lo, bias, cout, mode)
+            e.record(torch.cuda.current_stream(x.device))
+            B, cin, H, W = x.shape
+            self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))
+            return y
+        convmod._launch = timed
+
+    def summary(self):
+        if not self.rec:
+            return None
+        us = sum(s.elapsed_time(e) * 1e3 for s, e, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return us / len(self.rec), fl / len(self.rec), fl / us / 1e6   # avg us, avg flops, TFLOP/s
 
 
 def pmc_traffic(workload, dtype):
@@ -167,7 +200,7 @@ def main():
         dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
-    from doubleattentionspeakerverification_amd import _lib, poolings
+    from doubleattentionspeakerverification_amd import _lib, poolings, conv as convmod
     from doubleattentionspeakerverification_amd.model import SpeakerClassifier
     lib = _lib.load()  # raises if the HIP library is missing
 
@@ -179,6 +212,7 @@ def main():
     B, T = args.batch, args.frames
     rs = np.random.RandomState(1234 + rank)
     timer = PoolTimer(poolings)
+    ctimer = ConvTimer(convmod)
     compute_dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     config = {}
 
@@ -245,6 +279,7 @@ def main():
     run_steps(0, args.warmup)
     barrier()
     timer.active = True
+    ctimer.active = True
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -254,6 +289,7 @@ def main():
     region_ms = ev0.elapsed_time(ev1)
     elapsed = time.perf_counter() - t0
     timer.active = False
+    ctimer.active = False
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -265,14 +301,27 @@ def main():
         pool_us = timer.mean_us()
         if args.workload == "pool":   # back-to-back launches on one stream: events around the whole timed region
             pool_us = region_ms * 1e3 / args.steps
-        roofline = None
+        pool_roof = None
         if pool_us:
             ach = abytes / pool_us / 1e3  # GB/s
-            roofline = {"kernel": "dasv::dmha_fwd_vec (fused DoubleMHA forward)", "bound": "hbm", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": pmc_traffic(args.workload, args.dtype),
-                        "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(pool_us, 3),
-                        "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_debug_last_variant().decode()}
+            pool_roof = {"kernel": "dasv::dmha_fwd_vec (fused DoubleMHA forward)", "bound": "hbm", "achieved": round(ach, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(args.workload, args.dtype),
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(pool_us, 3),
+                         "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_debug_last_variant().decode()}
+        roofline = pool_roof
+        csum = ctimer.summary()
+        if csum is not None:
+            # the step is dominated (~90 %) by the hand-written conv3x3 launches: MFMA-bound
+            avg_us, avg_fl, tfs = csum
+            mult = 3 if args.conv == "split" else 1
+            roofline = {"kernel": "dasv::conv3x3_window_kernel (implicit-GEMM conv3x3+bias+ReLU, %s operands)" % args.conv,
+                        "bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+                        "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4), "traffic": None,
+                        "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
+                        "launches_per_step": len(ctimer.rec) // max(1, args.steps),
+                        "mfma_flops_executed_per_algorithmic_flop": mult,
+                        "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
@@ -286,7 +335,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if compute_dtype == torch.float32 else "bf16",
             "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
-            "config": config, "roofline": roofline, "cpu_baseline": cpu,
+            "config": config, "roofline": roofline, "roofline_pooling": pool_roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
 // LDS: A_hi | A_lo windows of `wrows` x 128 B, then B_hi | B_lo tiles of 128 x 128 B.
 constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 511) / 512;
 
-template <bool SPLIT>
+template <bool SPLIT, bool DBUF>
 __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -239,8 +239,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     const int wrows = WBM + 2 * W + 2;
     char* Ahi = smem;
     char* Alo = Ahi + (size_t)wrows * 128;
-    char* Bhi = Alo + (SPLIT ? (size_t)wrows * 128 : 0);
-    char* Blo = Bhi + 16384;
+    char* Bbase = Alo + (SPLIT ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tile = xcd * p.tiles_per_xcd + idx;
@@ -308,13 +307,13 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             if (SPLIT) rbl[k] = *reinterpret_cast<const u32x4*>(p.wlo + off);
         }
     };
-    auto store_b = [&]() {
+    auto store_b = [&](char* Bhi) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int q = tid + 512 * k;
             const int o = lds_off(q >> 3, q & 7);
             *reinterpret_cast<u32x4*>(Bhi + o) = rbh[k];
-            if (SPLIT) *reinterpret_cast<u32x4*>(Blo + o) = rbl[k];
+            if (SPLIT) *reinterpret_cast<u32x4*>(Bhi + 16384 + o) = rbl[k];
         }
     };
 
@@ -326,12 +325,17 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
 
     const int nslab = Cin / CBK;
     load_b(0, 0);
+    int it = 0;
     for (int sl = 0; sl < nslab; ++sl) {
         const int c0 = sl * CBK;
-        load_window(c0);                      // previous slab's readers are behind the barrier that ended its last tap
+        load_window(c0);
+        if (DBUF && sl > 0) __syncthreads();   // every wave is done reading the previous slab's window
         store_window();
-        for (int tap = 0; tap < 9; ++tap) {
-            store_b();
+        for (int tap = 0; tap < 9; ++tap, ++it) {
+            // DBUF: the buffer written now was last read two iterations ago, and every wave passed the barrier of
+            // the previous iteration only after finishing that read -> ONE barrier per tap.
+            char* Bhi = Bbase + ((DBUF && (it & 1)) ? 32768 : 0);
+            store_b(Bhi);
             __syncthreads();
             if (tap < 8) load_b(tap + 1, c0);
             else if (sl + 1 < nslab) load_b(0, c0 + CBK);
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                 for (int j = 0; j < 4; ++j) {
                     const int o = lds_off(wn * 64 + j * 16 + frow, slot);
                     bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + o);
-                    if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Blo + o);
+                    if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Bhi + 16384 + o);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -358,32 +362,33 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                     if (SPLIT) al = ok ? al : zero;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                        // weights as the A operand, pixels as B: the 16x16 result has channels on its rows, so a
+                        // lane ends up with 4 consecutive channels of one pixel (16-byte stores in the epilogue)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
                         if (SPLIT) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
                         }
                     }
                 }
             }
-            __syncthreads();
+            if (!DBUF) __syncthreads();
         }
     }
 
+    // epilogue: D[row = channel][col = pixel]: lane holds channels n .. n+3 of pixel m
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (m < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[(size_t)m * p.Cout + n] = v;
-                }
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m < p.M) {
+                f32x4 v = acc[i][j] + bv;
+                if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
             }
         }
     }
@@ -426,14 +431,22 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
-        const size_t lds = (size_t)wrows * 128 * (mode == 0 ? 2 : 1) + 32768;
+        const size_t lds1 = (size_t)wrows * 128 * (mode == 0 ? 2 : 1) + 32768;
+        const bool dbuf = mode == 0 && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
+        const size_t lds = lds1 + (dbuf ? 32768 : 0);
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(512);
-        const void* fn = mode == 0 ? reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<true>)
-                                   : reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        if (mode == 0) hipLaunchKernelGGL(dasv::conv3x3_window_kernel<true>, grid, block, lds, s, p);
-        else hipLaunchKernelGGL(dasv::conv3x3_window_kernel<false>, grid, block, lds, s, p);
+#define DASV_LAUNCH_WINDOW(SP, DB)                                                                                   \
+        do {                                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB>),   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+            if (e != hipSuccess) return (int)e;                                                                      \
+            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB>), grid, block, lds, s, p);                        \
+        } while (0)
+        if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true);
+        else if (mode == 0) DASV_LAUNCH_WINDOW(true, false);
+        else if (dbuf) DASV_LAUNCH_WINDOW(false, true);
+        else DASV_LAUNCH_WINDOW(false, false);
+#undef DASV_LAUNCH_WINDOW
         return (int)hipGetLastError();
     }
     p.mtiles = (p.M + dasv::CBM - 1) / dasv::CBM;

@@ -250,3 +250,35 @@ def test_hip_conv11_and_maxpool_match_torch():
         pr = torch.nn.functional.max_pool2d(t, 2, stride=2, ceil_mode=True)
         pm = conv.maxpool2x2_ceil(t)
         assert pm.shape == pr.shape and torch.equal(pm, pr)
+
+
+def test_hip_conv_wide_map_uses_tile_kernel_and_matches():
+    """W > 80 does not fit the window kernel's LDS budget: the per-tap tile kernel takes over, same results."""
+    from doubleattentionspeakerverification_amd import conv
+    x = torch.relu(torch.from_numpy(rnd(31, 2, 64, 5, 97))).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.from_numpy(rnd(32, 128, 64, 3, 3, scale=0.06)).to(DEV)
+    b = torch.from_numpy(rnd(33, 128, scale=0.1)).to(DEV)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))
+    with torch.no_grad():
+        y = conv.conv3x3_bias_relu(x, w, b, None, "split").cpu().double()
+    assert float((y - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+
+
+def test_frontend_hip_path_equals_torch_path_on_default_width():
+    """VGG4L at kernel_size 1024 (the reference default): all-HIP inference front-end vs PyTorch-ROCm convs."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    torch.manual_seed(3)
+    net = VGG4L(1024).to(DEV).eval()
+    x = torch.from_numpy(rnd(41, 2, 77, 80)).to(DEV)
+    with torch.no_grad():
+        net.conv_mode = "torch"
+        ref = net(x)
+        net.conv_mode = "split"
+        y = net(x)
+        net.conv_mode = "bf16"
+        yb = net(x)
+    assert y.shape == ref.shape == (2, 5, 5120)
+    rel = float((y - ref).abs().max() / ref.abs().max())
+    relb = float((yb - ref).abs().max() / ref.abs().max())
+    print("front-end output: split-vs-torch rel err %.2e, bf16-vs-torch %.2e" % (rel, relb))
+    assert rel < 5e-5 and relb < 3e-2
