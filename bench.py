@@ -83,12 +83,12 @@ class ConvTimer:
         self.active = False
         inner = convmod._launch
 
-        def timed(x, hi, lo, bias, cout, mode):
+        def timed(x, hi, lo, bias, cout, mode, relu=1):
             if not self.active:
-                return inner(x, hi, lo, bias, cout, mode)
+                return inner(x, hi, lo, bias, cout, mode, relu)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(torch.cuda.current_stream(x.device))
-            y = inner(x, hi, lo, bias, cout, mode)
+            y = inner(x, hi, lo, bias, cout, mode, relu)
             e.record(torch.cuda.current_stream(x.device))
             B, cin, H, W = x.shape
             self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))
@@ -184,6 +184,9 @@ def main():
                     help="front-end convolutions: hand-written MFMA implicit GEMM with split-bf16 operands (fp32-grade, "
                          "default) or bf16 operands, or PyTorch-ROCm/MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) for real runs; gloo only to rehearse the multi-rank path on one GPU")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,13 +194,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
 
     from doubleattentionspeakerverification_amd import _lib, poolings, conv as convmod

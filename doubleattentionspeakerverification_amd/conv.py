@@ -43,13 +43,13 @@ class PackedConvWeights:
         return self.hi, self.lo
 
 
-def _launch(x, hi, lo, bias, cout, mode):
+def _launch(x, hi, lo, bias, cout, mode, relu=1):
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                             None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout, 1,
+                                             None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout, relu,
                                              torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_nhwc")
     return y
@@ -62,15 +62,33 @@ class _ConvReLUFn(torch.autograd.Function):
         y = _launch(x, hi, lo, bias, weight.shape[0], mode)
         ctx.save_for_backward(x, weight, y)
         ctx.has_bias = bias is not None
+        ctx.mode = mode
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        g = gy * (y > 0)
-        gx, gw, gb = torch.ops.aten.convolution_backward(
-            g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        g = (gy * (y > 0)).contiguous(memory_format=torch.channels_last)
+        cout, cin = weight.shape[0], weight.shape[1]
+        gx = None
+        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_x and supported(cout, cin) and g.dtype == torch.float32:
+            # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution of g with the weights
+            # transposed over (Cout, Cin) and flipped over (ky, kx): reuse the forward implicit-GEMM kernel
+            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
+            pk = PackedConvWeights()
+            hi, lo = pk.get(wt)
+            gx = _launch(g, hi, lo, None, cin, ctx.mode, relu=0)
+            want_x = False
+        if want_x or want_w or want_b:
+            gx2, gw, gb = torch.ops.aten.convolution_backward(
+                g, x, weight, [cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [want_x, want_w, want_b])
+            if gx is None:
+                gx = gx2
+        else:
+            gw = gb = None
         return gx, gw, gb, None, None
 
 

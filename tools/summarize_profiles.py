@@ -14,8 +14,8 @@ KERNEL = "dasv::dmha_fwd_vec"
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # newest run wins
+    return g[-1] if g else None
 
 
 def stats(run):
@@ -69,9 +69,25 @@ for run in ("pool", "embed"):
                   % (f / 1e6, w / 1e6, hbm / 1e6, alg[run] / 1e6, hbm / alg[run]))
         md.append("* algorithmic bytes / kernel time = %.0f GB/s = %.1f %% of 8 TB/s (spec), %.1f %% of 6.29 TB/s (measured copy peak)\n"
                   % (alg[run] / avg / 1e3, alg[run] / avg / 1e3 / 80, alg[run] / avg / 1e3 / 62.9))
+    if run == "embed":
+        rows = list(csv.DictReader(open(one("embed_trace/*/*kernel_stats.csv"))))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        steps = 8.0  # warmup 2 + steps 6 in tools/collect_profiles.sh
+        md.append("* kernel mix of the step (all GPU kernels, %.2f ms of kernel time per step):\n" % (tot / steps / 1e6))
+        for r in rows[:8]:
+            md.append("  * `%s` — %s calls, avg %.1f us, %.1f %% of kernel time\n"
+                      % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+        conv = [r for r in rows if "conv3x3_window_kernel" in r["Name"]]
+        if conv:
+            per_step = sum(float(c["TotalDurationNs"]) for c in conv) / steps / 1e3
+            flops = 64 * (39.13e9 - 0.055e9)   # seven wide layers of VGG4L/1024 at T=300 (SURVEY appendix D.1 minus conv11)
+            md.append("* `conv3x3_window_kernel`: %.0f us per step over 7 launches -> %.0f TFLOP/s algorithmic (x3 executed on the "
+                      "MFMA pipe in split mode = %.0f TFLOP/s, %.0f %% of the 2.5 PFLOP/s dense bf16 peak)\n"
+                      % (per_step, flops / per_step / 1e6, 3 * flops / per_step / 1e6, 100 * 3 * flops / per_step / 1e6 / 2500))
     if bl:
-        md.append("* bench.py under the profiler: value %.1f %s, roofline avg_launch_us %.2f (events; includes inter-launch gaps)\n"
-                  % (bl["value"], bl["unit"], bl["roofline"]["avg_launch_us"]))
+        pr = bl.get("roofline_pooling") or bl["roofline"]
+        md.append("* bench.py under the profiler: value %.1f %s; pooling-kernel avg_launch_us %.2f by events (includes the event/launch gap)\n"
+                  % (bl["value"], bl["unit"], pr["avg_launch_us"]))
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("".join(md))
 print("".join(md))
