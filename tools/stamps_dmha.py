@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--tuning", default="0,0,0,0", help="nw,wpu,ldspad,rows")
     ap.add_argument("--no-att", action="store_true")
     ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--nbuf", type=int, default=8)
     args = ap.parse_args()
     if args.build:
         build()
@@ -46,7 +47,7 @@ def main():
     B, T, D, H = (int(v) for v in args.shape.split(","))
     dh = D // H
     dev = torch.device("cuda:0")
-    nbuf = 8
+    nbuf = args.nbuf
     xs = [torch.randn(B, T, D, device=dev) for _ in range(nbuf)]
     q = torch.randn(dh, H, device=dev) * 0.2
     a = torch.randn(dh, device=dev) * 0.2

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--nbuf", type=int, default=0, help="number of rotating input buffers (default: enough for > 300 MB)")
     ap.add_argument("--no-att", action="store_true", help="per-head stage only (no in-launch head exchange)")
     ap.add_argument("--configs", default="", help="semicolon list of nw,wpu,pad,rows tuples to time instead of the default sweep")
     args = ap.parse_args()
@@ -55,7 +56,7 @@ def main():
     esize = 4 if dt == torch.float32 else 2
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    nbuf = max(8, int(np.ceil(300e6 / (B * T * D * esize))))
+    nbuf = args.nbuf if args.nbuf > 0 else max(8, int(np.ceil(300e6 / (B * T * D * esize))))
     g = torch.Generator(device=dev).manual_seed(1234)
     xs = [torch.randn(B, T, D, device=dev, generator=g).to(dt) for _ in range(nbuf)]
     q = torch.randn(dh, H, device=dev, generator=g) * (2.0 / (dh + H)) ** 0.5
