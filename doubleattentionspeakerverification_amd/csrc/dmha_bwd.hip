@@ -30,6 +30,7 @@ struct BwdParams {
     void* gx;
     float* part_q;          // [B][H*dh] per-utterance partial sums of gs*x
     float* gu;              // [B][H]
+    float* part_a;          // [B*arrivals][dh] per-workgroup partial sums of gu*c (vector kernel) / [B*H][dh] (generic)
     long long sb, st;
     int B, T, H, dh;
     int wpu, upw, arrivals;
@@ -64,6 +65,38 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
     int len = T;
     if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
 
+    const size_t unit_off = ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
+    const char* xrow = static_cast<const char*>(p.x) + unit_off;
+    char* gxrow = static_cast<char*>(p.gx) + unit_off;
+    const size_t row_bytes = (size_t)p.st * E::kBytes;
+
+    float gq[NI][EPV];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) gq[j][e] = 0.f;
+
+    const int rows_per_pass = P * R;
+    const int npass = (T + rows_per_pass - 1) / rows_per_pass;
+
+    auto load_pass = [&](uint4 (&buf)[R][NI], int pass) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int t = phase + P * (pass * R + i);
+            const bool valid = t < len;
+            const char* rp = xrow + (size_t)t * row_bytes;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * G * 16);
+                buf[i][j] = v;
+            }
+        }
+    };
+    // memory operations return in issue order: the first rows of x go out before the (dependent) prologue loads
+    uint4 bufA[R][NI], bufB[R][NI];
+    if (npass > 0) load_pass(bufA, 0);
+
     // per-lane fragments of q, gc for this lane's columns
     float q[NI][EPV], gc[NI][EPV];
     float gcc = 0.f;
@@ -93,7 +126,10 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
             const float gwh = group_sum<G>(gwp), gdot = group_sum<G>(gdp);
             const float wh = p.head_w[(size_t)b * H + h];
             const float guh = wh * (gwh - gdot);
-            if (wu == 0 && lane == 0) p.gu[(size_t)b * H + h] = guh;
+            if (wu == 0 && lane == 0) {
+                p.gu[(size_t)b * H + h] = guh;
+                smem[(size_t)p.upw * P * dh + uu] = guh;   // read back after the stream for the grad_att partial row
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -116,34 +152,6 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
     const float Mu = (M == -INFINITY) ? 0.f : M;
     const float invL = (Lsum > 0.f) ? 1.0f / Lsum : 0.f;
 
-    const size_t unit_off = ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
-    const char* xrow = static_cast<const char*>(p.x) + unit_off;
-    char* gxrow = static_cast<char*>(p.gx) + unit_off;
-    const size_t row_bytes = (size_t)p.st * E::kBytes;
-
-    float gq[NI][EPV];
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) gq[j][e] = 0.f;
-
-    const int rows_per_pass = P * R;
-    const int npass = (T + rows_per_pass - 1) / rows_per_pass;
-
-    auto load_pass = [&](uint4 (&buf)[R][NI], int pass) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int t = phase + P * (pass * R + i);
-            const bool valid = t < len;
-            const char* rp = xrow + (size_t)t * row_bytes;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * G * 16);
-                buf[i][j] = v;
-            }
-        }
-    };
     auto compute_pass = [&](const uint4 (&buf)[R][NI], int pass) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -178,37 +186,45 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
         }
     };
 
-    uint4 bufA[R][NI], bufB[R][NI];
-    if (npass > 0) load_pass(bufA, 0);
+    if (npass > 1) load_pass(bufB, 1);
     for (int pass = 0; pass < npass; pass += 2) {
-        if (pass + 1 < npass) load_pass(bufB, pass + 1);
         compute_pass(bufA, pass);
+        if (pass + 2 < npass) load_pass(bufA, pass + 2);
         if (pass + 1 < npass) {
-            if (pass + 2 < npass) load_pass(bufA, pass + 2);
             compute_pass(bufB, pass + 1);
+            if (pass + 3 < npass) load_pass(bufB, pass + 3);
         }
     }
 
-    // sum gq over the groups of the wave, then over the waves of the unit (fixed order)
-#pragma unroll
-    for (int off = G; off < 64; off <<= 1)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) gq[j][e] += __shfl_xor(gq[j][e], off);
-    float* red = smem;  // [nw][dh]
-    if (lane < G) {
+    // every row phase parks its partial sum in its own LDS slot; the unit's first wave adds them in a fixed order
+    float* red = smem;  // [upw*P][dh]
+    {
+        float* rs = red + (size_t)(uu * P + phase) * dh;
+        typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) red[(size_t)w * dh + (c + G * j) * EPV + e] = gq[j][e];
+            for (int e = 0; e < EPV; e += 4)
+                *reinterpret_cast<f4*>(rs + (c + G * j) * EPV + e) = f4{gq[j][e], gq[j][e + 1], gq[j][e + 2], gq[j][e + 3]};
     }
     __syncthreads();
-    const int w0 = uu * wpu, tu = wu * 64 + lane, nthr_u = wpu * 64;
-    for (int d = tu; d < dh; d += nthr_u) {
-        float v = 0.f;
-        for (int k = 0; k < wpu; ++k) v += red[(size_t)(w0 + k) * dh + d];
-        p.part_q[(size_t)b * H * dh + (size_t)h * dh + d] = v;
+    if (wu == 0) {
+        const float* ru = red + (size_t)uu * P * dh;
+        for (int d = lane; d < dh; d += 64) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int k2 = 0; k2 < P; ++k2) v += ru[(size_t)k2 * dh + d];
+            p.part_q[(size_t)b * H * dh + (size_t)h * dh + d] = v;
+        }
+    }
+    // grad_att: this workgroup's heads pre-reduced, sum_h gu[b,h] * c[b,h,:]  (one row per workgroup)
+    if (p.att != nullptr) {
+        const float* gus = smem + (size_t)p.upw * P * dh;
+        for (int d = tid; d < dh; d += blockDim.x) {
+            float v = 0.f;
+            for (int k2 = 0; k2 < p.upw; ++k2) v = fmaf(gus[k2], p.ctx[((size_t)b * H + a * p.upw + k2) * dh + d], v);
+            p.part_a[((size_t)b * p.arrivals + a) * dh + d] = v;
+        }
     }
 }
 
@@ -293,39 +309,42 @@ __global__ void __launch_bounds__(256) dmha_bwd_generic(const BwdParams p) {
             gq = fmaf(gs_l[t], xv, gq);
         }
         p.part_q[(size_t)b * H * dh + (size_t)h * dh + d] = gq;
+        if (p.att != nullptr) p.part_a[((size_t)b * H + h) * dh + d] = guh * ch[d];
     }
 }
 
-// grad_query[d,h] = rs * sum_b part_q[b][h*dh+d];  grad_att[d] = sum_{b,h} gu[b,h] ctx[b,h,d]
+// grad_query[d,h] = rs * sum_b part_q[b][h*dh+d];  grad_att[d] = sum_rows part_a[row][d]
+// 1024 threads = 64 columns x 16 row phases; each thread adds rows ph, ph+16, ... with independent loads in flight.
 struct ReduceParams {
-    const float* part_q; const float* gu; const float* ctx;
+    const float* part_q; const float* part_a;
     float* grad_query; float* grad_att;
-    int B, H, dh, nq_blocks; float rs;
+    int B, H, dh, nq_blocks, rows_a; float rs;
 };
-__global__ void __launch_bounds__(256) dmha_bwd_reduce(const ReduceParams p) {
-    __shared__ float red[4][64];
+__global__ void __launch_bounds__(1024) dmha_bwd_reduce(const ReduceParams p) {
+    __shared__ float red[16][64];
     const int col_l = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int D = p.H * p.dh;
-    if ((int)blockIdx.x < p.nq_blocks) {
-        const int col = blockIdx.x * 64 + col_l;
-        float v = 0.f;
-        if (col < D)
-            for (int b = ph; b < p.B; b += 4) v += p.part_q[(size_t)b * D + col];
-        red[ph][col_l] = v;
-        __syncthreads();
-        if (ph == 0 && col < D) {
-            const float s = ((red[0][col_l] + red[1][col_l]) + red[2][col_l]) + red[3][col_l];
+    const bool is_q = (int)blockIdx.x < p.nq_blocks;
+    const int col = (is_q ? blockIdx.x : blockIdx.x - p.nq_blocks) * 64 + col_l;
+    const int ncol = is_q ? D : p.dh, nrow = is_q ? p.B : p.rows_a;
+    const float* src = is_q ? p.part_q : p.part_a;
+    float v = 0.f;
+    if (col < ncol) {
+#pragma unroll 4
+        for (int r = ph; r < nrow; r += 16) v += src[(size_t)r * ncol + col];
+    }
+    red[ph][col_l] = v;
+    __syncthreads();
+    if (ph == 0 && col < ncol) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][col_l];
+        if (is_q) {
             const int h = col / p.dh, d = col - h * p.dh;
             p.grad_query[(size_t)d * p.H + h] = s * p.rs;
+        } else {
+            p.grad_att[col] = s;
         }
-    } else if (p.grad_att != nullptr) {
-        const int d = (blockIdx.x - p.nq_blocks) * 64 + col_l;
-        float v = 0.f;
-        if (d < p.dh)
-            for (int r = ph; r < p.B * p.H; r += 4) v = fmaf(p.gu[r], p.ctx[(size_t)r * p.dh + d], v);
-        red[ph][col_l] = v;
-        __syncthreads();
-        if (ph == 0 && d < p.dh) p.grad_att[d] = ((red[0][col_l] + red[1][col_l]) + red[2][col_l]) + red[3][col_l];
     }
 }
 
@@ -373,7 +392,8 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
     p.x = x; p.query = query; p.att = att; p.lengths = lengths; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
     p.out = out; p.go = go; p.gx = gx;
     p.part_q = static_cast<float*>(workspace);
-    p.gu = p.part_q + (size_t)B * H * dh;
+    p.part_a = p.part_q + (size_t)B * H * dh;
+    p.gu = p.part_a + (size_t)B * H * dh;
     p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
@@ -396,13 +416,15 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
         const int gpw = 64 / G;
         const int rpp = bwd_rows_per_pass_for(NI);
         int wpu = 1;
-        while (wpu < 8 && wpu * gpw * rpp * 4 < T) wpu <<= 1;
-        int nw = wpu >= 4 ? wpu : 4;
-        nw = nw / wpu * wpu;
-        const int upw = bwd_largest_divisor_leq(H, nw / wpu);
+        while (wpu < 8 && wpu * gpw * rpp * 5 < T) wpu <<= 1;
+        int nw = 8;
+        if (nw < wpu) nw = wpu;
+        int upw = bwd_largest_divisor_leq(H, nw / wpu);
+        while (upw > 1 && (long long)groups8 * (H / upw) < 256) upw = bwd_largest_divisor_leq(H, upw - 1);
+        while (upw * wpu > 4 && upw > 1 && (long long)groups8 * (H / upw) > 1024) upw = bwd_largest_divisor_leq(H, upw - 1);
         nw = upw * wpu;
         p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
-        const size_t lds = (size_t)nw * dh * sizeof(float);
+        const size_t lds = ((size_t)upw * wpu * gpw * dh + 8) * sizeof(float);
         if (lds <= 64 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
             launched = dispatch_bwd_vec<XT>(G, NI, p, grid, block, lds, stream, err);
@@ -419,12 +441,13 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
     if (err != hipSuccess) return (int)err;
 
     ReduceParams r;
-    r.part_q = p.part_q; r.gu = p.gu; r.ctx = ctx; r.grad_query = grad_query;
+    r.part_q = p.part_q; r.part_a = p.part_a; r.grad_query = grad_query;
     r.grad_att = (att != nullptr) ? grad_att : nullptr;
     r.B = B; r.H = H; r.dh = dh; r.rs = p.rs;
+    r.rows_a = B * p.arrivals;
     r.nq_blocks = (H * dh + 63) / 64;
     const int na_blocks = (att != nullptr) ? (dh + 63) / 64 : 0;
-    hipLaunchKernelGGL(dmha_bwd_reduce, dim3((unsigned)(r.nq_blocks + na_blocks)), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(dmha_bwd_reduce, dim3((unsigned)(r.nq_blocks + na_blocks)), dim3(1024), 0, stream, r);
     return (int)hipGetLastError();
 }
 
@@ -435,7 +458,8 @@ extern "C" {
 size_t dasv_dmha_bwd_workspace_bytes(int B, int T, int H, int dh) {
     (void)T;
     if (B <= 0 || H <= 0 || dh <= 0) return 0;
-    return ((size_t)B * H * dh + (size_t)dasv::round_up_i(B * H, 4)) * sizeof(float);
+    // per-utterance grad_query partial rows | per-workgroup grad_att partial rows | gu
+    return ((size_t)2 * B * H * dh + (size_t)dasv::round_up_i(B * H, 4)) * sizeof(float);
 }
 
 int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* att, const uint8_t* head_keep,
