@@ -66,9 +66,10 @@ class _VGG(nn.Module):
                    and _hipconv.supported(conv.in_channels, conv.out_channels))
         if not use_hip:
             return F.relu(conv(h))
-        packed = self._packed.get(name)
+        key = (name, h.device.index)   # nn.DataParallel replicas share this dict: one packed copy per device
+        packed = self._packed.get(key)
         if packed is None:
-            packed = self._packed[name] = _hipconv.PackedConvWeights()
+            packed = self._packed[key] = _hipconv.PackedConvWeights()
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode)
 
     def _hip_inference(self, x):
