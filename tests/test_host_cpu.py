@@ -156,3 +156,32 @@ def test_length_bucketing_and_dealing():
     assert deal_buckets(buckets, lengths, 8) == parts               # deterministic
     with pytest.raises(ValueError):
         bucket_by_length([10, 0, 3])
+
+
+def test_utils_helpers_match_reference_vectors(tmp_path):
+    from doubleattentionspeakerverification_amd import utils
+    g = load_golden("g6_scoring")
+    assert utils.calculate_EER(g["eer_clients"], g["eer_impostors"]) == float(g["eer"])
+    assert utils.calculate_EER(np.full(10, 0.9), np.full(10, -0.9)) == float(g["eer_separated"])
+    rs = np.random.RandomState(0)
+    cl, im = rs.normal(0.6, 0.15, 2000), rs.normal(0.1, 0.15, 2000)
+    for t, far, frr in zip(g["score_th"], g["score_far"], g["score_frr"]):
+        assert utils.Score(im, t, "FAR") == far and utils.Score(list(cl), t, "FRR") == frr
+    cos = utils.scoreCosineDistance(torch.from_numpy(g["cos_e1"]), torch.from_numpy(g["cos_e2"]))
+    np.testing.assert_allclose(cos.numpy(), g["cos"], atol=1e-7)
+    assert utils.Accuracy(torch.from_numpy(g["acc_pred"]), torch.from_numpy(g["acc_label"])) == pytest.approx(float(g["acc"]))
+    ns = argparse.Namespace(model_name="CNN", front_end="VGG4L", window_size=3.5, batch_size=64, gradientAccumulation=2,
+                            learning_rate=0.0001, weight_decay=0.001, kernel_size=1024, embedding_size=400,
+                            scalingFactor=30.0, marginFactor=0.4, pooling_method="DoubleMHA", heads_number=32)
+    assert utils.getModelName(ns) == str(g["model_name"])
+    # checkpoint round trip in the reference's layout and naming
+    ns.out_dir, ns.model_name = str(tmp_path), "m"
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(net.parameters())
+    path = utils.chkptsave(ns, net, opt, 4, 99)
+    assert path.endswith("m_99.chkpt")
+    d = utils.load_checkpoint(path, torch.device("cpu"))
+    assert sorted(d) == ["epoch", "model", "optimizer", "settings", "step"] and d["settings"].kernel_size == 1024
+    lab = tmp_path / "labels.ndx"
+    lab.write_text("a/1 spk1 0\nb/2 spk2 1\nc/3 spk1 0\n")
+    assert utils.getNumberOfSpeakers(str(lab)) == 2
