@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libdasv_hip.so"
-SOURCES = ["dmha_fwd.hip", "dmha_bwd.hip", "conv3x3.hip", "frontend_misc.hip"]
+SOURCES = ["dmha_fwd.hip", "dmha_bwd.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "frontend_misc.hip"]
 HEADERS = ["dasv_common.hpp", os.path.join("..", "..", "include", "dasv_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -9,9 +9,11 @@ import torch
 
 from . import _lib
 
-__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil"]
+__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
+           "conv3x3_wgrad", "supported_wgrad"]
 
 MODES = {"split": 0, "bf16": 1}
+USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
 
 
 def supported(cin, cout):
@@ -55,6 +57,30 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1):
     return y
 
 
+def supported_wgrad(cin, cout, width=1):
+    return cin % 64 == 0 and cout % 64 == 0 and width <= 80
+
+
+def conv3x3_wgrad(x, g, mode="split"):
+    """Weight gradient [Cout,Cin,3,3] of conv3x3 (stride 1, pad 1) from x [B,Cin,H,W] and g [B,Cout,H,W]
+    (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip)."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    cout = g.shape[1]
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    if not g.is_contiguous(memory_format=torch.channels_last):
+        g = g.contiguous(memory_format=torch.channels_last)
+    gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    nbytes = lib.dasv_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_wgrad_nhwc(MODES[mode], x.data_ptr(), g.data_ptr(), gw.data_ptr(), ws.data_ptr(), nbytes,
+                                         B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_wgrad_nhwc")
+    return gw
+
+
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mode):
@@ -81,14 +107,20 @@ class _ConvReLUFn(torch.autograd.Function):
             hi, lo = pk.get(wt)
             gx = _launch(g, hi, lo, None, cin, ctx.mode, relu=0)
             want_x = False
+        gw = gb = None
+        if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3]) and g.dtype == torch.float32:
+            gw = conv3x3_wgrad(x, g, ctx.mode)
+            want_w = False
+            if want_b:
+                gb = g.sum(dim=(0, 2, 3))
+                want_b = False
         if want_x or want_w or want_b:
-            gx2, gw, gb = torch.ops.aten.convolution_backward(
+            gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
                 g, x, weight, [cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                 [want_x, want_w, want_b])
-            if gx is None:
-                gx = gx2
-        else:
-            gw = gb = None
+            gx = gx2 if want_x else gx
+            gw = gw2 if want_w else gw
+            gb = gb2 if want_b else gb
         return gx, gw, gb, None, None
 
 

@@ -143,6 +143,15 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 
+/* Weight gradient of the same convolution: gw[Cout,Cin,3,3] (torch layout, OVERWRITTEN) from x [B,H,W,Cin] and
+ * g [B,H,W,Cout] = gradient w.r.t. the convolution output (ReLU mask applied by the caller), both NHWC fp32.
+ * Replaces autograd's weight gradient of `F.relu(self.convXY(x))` (CNNs.py:38-48 / 72-86; loss.backward(), train.py:220).
+ * Cin % 64 == 0, Cout % 64 == 0; modes as above; workspace: dasv_conv3x3_wgrad_workspace_bytes(), no init needed.
+ * Deterministic (fixed-order split-K reduction, no atomics). */
+size_t dasv_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw, void* workspace, size_t workspace_bytes,
+                            int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+
 /* conv3x3 with ONE input channel (+ bias + ReLU): x [B,H,W] fp32 -> y [B,H,W,Cout] NHWC fp32.  Replaces
  * `F.relu(self.conv11(x))` (CNNs.py:38 / 72); w is the torch weight [Cout,1,3,3].  Cout % 4 == 0, (Cout/4) | 256. */
 int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
