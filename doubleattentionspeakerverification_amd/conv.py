@@ -94,7 +94,8 @@ class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        g = (gy * (y > 0)).contiguous(memory_format=torch.channels_last)
+        # ReLU backward in one pass (g = gy where y > 0 else 0)
+        g = torch.ops.aten.threshold_backward(gy.contiguous(memory_format=torch.channels_last), y, 0.0)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = None
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
