@@ -4,11 +4,13 @@
         .getEmbedding(x [B,T,80]) -> [B, embedding_size]                     model.py:52-59
         .forward(x, label=None, step=0) -> (costh, scaled margin logits)     model.py:61-71
 
-Reads from ``parameters``: front_end, kernel_size, pooling_method, heads_number, mask_prob,
-embedding_size, num_spkrs, scalingFactor, marginFactor, annealing; writes feature_size = 80
-(model.py:13).  Sub-module names (front_end, poolingLayer, fc1, b1, fc2, b2, preLayer, b3,
-predictionLayer) and therefore state_dict keys equal the reference's; b1 and b3 exist but are
-unused there too (model.py:46,50).
+Reads from ``parameters``: front_end, kernel_size, pooling_method, heads_number, mask_prob, embedding_size, num_spkrs,
+scalingFactor, marginFactor, annealing; writes feature_size = 80 (model.py:13).  The sub-module names — front_end,
+poolingLayer, fc1, b1, fc2, b2, preLayer, b3, predictionLayer — are the drop-in contract (state_dict keys of reference
+checkpoints); b1 and b3 are registered but never called, exactly like upstream (model.py:46,50), so they carry no gradient.
+
+Data flow on the GPU: NHWC fp32 front-end on the hand-written conv / pool kernels -> ONE fused DoubleMHA launch (the
+[B,T,H] alignments are not materialised on this path) -> two small dense layers and BatchNorm through PyTorch-ROCm.
 """
 import argparse
 
@@ -16,72 +18,73 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .poolings import *  # noqa: F401,F403  (callers rely on `from model import *`)
-from .CNNs import *  # noqa: F401,F403
+from . import CNNs as _cnns
+from . import loss as _loss
+from . import poolings as _pool
+from .CNNs import *  # noqa: F401,F403  (callers rely on `from model import *` re-exporting everything)
 from .loss import *  # noqa: F401,F403
-from .poolings import Attention, DoubleMHA, MultiHeadAttention
-from .CNNs import VGG3L, VGG4L, getVGG3LOutputDimension, getVGG4LOutputDimension
-from .loss import AMSoftmax
+from .poolings import *  # noqa: F401,F403
 
-# getEmbeddingExample.py:27 calls torch.load() on a checkpoint holding an argparse.Namespace;
-# torch >= 2.6 defaults to weights_only=True, which needs the class allow-listed.
-try:
+# getEmbeddingExample.py:27 calls torch.load() on a checkpoint holding an argparse.Namespace; torch >= 2.6 defaults to
+# weights_only=True, which needs the class allow-listed.
+if hasattr(torch.serialization, "add_safe_globals"):
     torch.serialization.add_safe_globals([argparse.Namespace])
-except AttributeError:  # older torch: nothing to do
-    pass
+
+MEL_BINS = 80
+
+# front_end name -> (module class, output-dimension helper)
+_FRONT_ENDS = {
+    "VGG3L": (_cnns.VGG3L, _cnns.getVGG3LOutputDimension),
+    "VGG4L": (_cnns.VGG4L, _cnns.getVGG4LOutputDimension),
+}
+
+
+def _make_pooling(method, width, heads, mask_prob):
+    """-> (pooling module, width of the pooled vector)."""
+    if method == "Attention":
+        return _pool.Attention(width), width
+    if method == "MHA":
+        return _pool.MultiHeadAttention(width, heads), width
+    if method == "DoubleMHA":
+        return _pool.DoubleMHA(width, heads, mask_prob=mask_prob), width // heads
+    raise ValueError("unknown pooling_method %r" % (method,))
 
 
 class SpeakerClassifier(nn.Module):
     def __init__(self, parameters, device):
         super().__init__()
-        parameters.feature_size = 80
+        parameters.feature_size = MEL_BINS
         self.device = device
-        self._init_front_end(parameters)
-        self._init_pooling(parameters)
-        self._init_fc(parameters)
-        self.predictionLayer = AMSoftmax(parameters.embedding_size, parameters.num_spkrs,
-                                         s=parameters.scalingFactor, m=parameters.marginFactor,
-                                         annealing=parameters.annealing)
+        self.pooling_method = parameters.pooling_method
+        emb = parameters.embedding_size
 
-    def _init_front_end(self, p):
-        if p.front_end == "VGG3L":
-            self.vector_size = getVGG3LOutputDimension(p.feature_size, outputChannel=p.kernel_size)
-            self.front_end = VGG3L(p.kernel_size)
-        if p.front_end == "VGG4L":
-            self.vector_size = getVGG4LOutputDimension(p.feature_size, outputChannel=p.kernel_size)
-            self.front_end = VGG4L(p.kernel_size)
+        front_cls, out_dim = _FRONT_ENDS[parameters.front_end]
+        self.front_end = front_cls(parameters.kernel_size)
+        frame_width = out_dim(parameters.feature_size, outputChannel=parameters.kernel_size)
+        self.poolingLayer, self.vector_size = _make_pooling(parameters.pooling_method, frame_width,
+                                                            parameters.heads_number, parameters.mask_prob)
+        # registration order below fixes the state_dict key order of the reference: fc1, b1, fc2, b2, preLayer, b3
+        for name, layer in (("fc1", nn.Linear(self.vector_size, emb)), ("b1", nn.BatchNorm1d(emb)),
+                            ("fc2", nn.Linear(emb, emb)), ("b2", nn.BatchNorm1d(emb)),
+                            ("preLayer", nn.Linear(emb, emb)), ("b3", nn.BatchNorm1d(emb))):
+            self.add_module(name, layer)
+        self.predictionLayer = _loss.AMSoftmax(emb, parameters.num_spkrs, s=parameters.scalingFactor,
+                                               m=parameters.marginFactor, annealing=parameters.annealing)
 
-    def _init_pooling(self, p):
-        self.pooling_method = p.pooling_method
-        if self.pooling_method == "Attention":
-            self.poolingLayer = Attention(self.vector_size)
-        elif self.pooling_method == "MHA":
-            self.poolingLayer = MultiHeadAttention(self.vector_size, p.heads_number)
-        elif self.pooling_method == "DoubleMHA":
-            self.poolingLayer = DoubleMHA(self.vector_size, p.heads_number, mask_prob=p.mask_prob)
-            self.vector_size = self.vector_size // p.heads_number
-
-    def _init_fc(self, p):
-        self.fc1 = nn.Linear(self.vector_size, p.embedding_size)
-        self.b1 = nn.BatchNorm1d(p.embedding_size)
-        self.fc2 = nn.Linear(p.embedding_size, p.embedding_size)
-        self.b2 = nn.BatchNorm1d(p.embedding_size)
-        self.preLayer = nn.Linear(p.embedding_size, p.embedding_size)
-        self.b3 = nn.BatchNorm1d(p.embedding_size)
-
-    def _pooled(self, x):
-        enc = self.front_end(x)
-        if isinstance(self.poolingLayer, DoubleMHA):
-            return self.poolingLayer.pool(enc)  # same launch, alignments not materialised
-        return self.poolingLayer(enc)[0]
+    def _utterance_vector(self, x):
+        frames = self.front_end(x)
+        pool = self.poolingLayer
+        if isinstance(pool, _pool.DoubleMHA):
+            return pool.pool(frames)           # same launch as forward(), alignments skipped
+        return pool(frames)[0]
 
     def getEmbedding(self, x):
-        e1 = F.relu(self.fc1(self._pooled(x)))
-        return self.b2(F.relu(self.fc2(e1)))
+        hidden = F.relu(self.fc1(self._utterance_vector(x)))
+        return self.b2(F.relu(self.fc2(hidden)))
 
     def forward(self, x, label=None, step=0):
-        e3 = self.preLayer(self.getEmbedding(x))
-        return self.predictionLayer(e3, label, step)
+        return self.predictionLayer(self.preLayer(self.getEmbedding(x)), label, step)
+
 
 __all__ = ["SpeakerClassifier", "new_parameter", "Attention", "HeadAttention", "innerKeyValueAttention",
            "MultiHeadAttention", "DoubleMHA", "getVGG3LOutputDimension", "getVGG4LOutputDimension",
