@@ -57,6 +57,10 @@ class _VGG(nn.Module):
             cin = cout
         self.channels_last = True
         self.conv_mode = "split"
+        # conv11 fused into conv12's window staging (one launch, conv11's 786 MB output never reaches HBM): correct and
+        # tested, but measured SLOWER end to end (6.74 vs 6.63 ms per [64,300,80] batch): conv12's loop is issue-bound and
+        # the nine extra FMAs per staged value cost more than the saved traffic.  Off by default.
+        self.fuse_first_block = False
         self._packed = {}
 
     def _conv_relu(self, name, h):
@@ -82,8 +86,20 @@ class _VGG(nn.Module):
     def forward(self, paddedInputTensor):
         B, T, Fdim = paddedInputTensor.shape
         hip = self._hip_inference(paddedInputTensor)
+        fused_first = False
         if hip:
-            h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias)
+            c12 = self.conv12
+            fused_first = (self.fuse_first_block and Fdim <= 80 and c12.weight.dtype == torch.float32
+                           and _hipconv.supported(c12.in_channels, c12.out_channels))
+            if fused_first:   # conv11 + conv12 in one launch: conv11's activations never reach HBM
+                key = ("conv12", paddedInputTensor.device.index)
+                packed = self._packed.get(key)
+                if packed is None:
+                    packed = self._packed[key] = _hipconv.PackedConvWeights()
+                h = _hipconv.conv3x3_c1_conv3x3_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias,
+                                                          c12.weight, c12.bias, packed, self.conv_mode)
+            else:
+                h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias)
         else:
             h = paddedInputTensor.reshape(B, 1, T, Fdim)
             if self.channels_last and h.is_cuda:
@@ -91,7 +107,8 @@ class _VGG(nn.Module):
         for blk in range(1, self.n_blocks + 1):
             if not (hip and blk == 1):
                 h = self._conv_relu("conv%d1" % blk, h)
-            h = self._conv_relu("conv%d2" % blk, h)
+            if not (fused_first and blk == 1):
+                h = self._conv_relu("conv%d2" % blk, h)
             h = _hipconv.maxpool2x2_ceil(h) if hip else F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
         return h.permute(0, 2, 1, 3).reshape(B, h.size(2), h.size(1) * h.size(3))

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
-           "conv3x3_wgrad", "supported_wgrad"]
+           "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu"]
 
 MODES = {"split": 0, "bf16": 1}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
@@ -164,4 +164,23 @@ def maxpool2x2_ceil(x):
     with torch.cuda.device(x.device):
         rc = lib.dasv_maxpool2x2_ceil_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_maxpool2x2_ceil_nhwc")
+    return y
+
+
+def conv3x3_c1_conv3x3_bias_relu(mel, w1, b1, weight2, bias2, packed=None, mode="split"):
+    """Inference-only first VGG block in one launch: relu(conv2(relu(conv1(mel[:,None])))) for mel [B,H,W] fp32, conv1 with
+    one input channel (its activations are produced while conv2's input window is staged and never reach HBM)."""
+    lib = _lib.load()
+    B, H, W = mel.shape
+    cmid, cout = weight2.shape[1], weight2.shape[0]
+    packed = packed or PackedConvWeights()
+    hi, lo = packed.get(weight2)
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=mel.device, memory_format=torch.channels_last)
+    with torch.cuda.device(mel.device):
+        rc = lib.dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(
+            MODES[mode], mel.contiguous().data_ptr(), w1.detach().contiguous().data_ptr(),
+            None if b1 is None else b1.detach().data_ptr(), hi.data_ptr(), lo.data_ptr(),
+            None if bias2 is None else bias2.detach().data_ptr(), y.data_ptr(), B, H, W, cmid, cout,
+            torch.cuda.current_stream(mel.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc")
     return y

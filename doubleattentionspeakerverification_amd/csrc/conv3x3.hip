@@ -68,6 +68,11 @@ struct ConvParams {
     int M;                 // B*H*W
     int mtiles, ntiles, tiles_per_xcd;
     int relu;
+    // fused one-channel producer (window kernel, C1 variant): x is not read; its values are
+    // relu(b1[c] + sum_tap w1[c][tap] * mel[pixel + tap]) computed while the window is staged
+    const float* mel;      // [B,H,W]
+    const float* w1;       // [Cin][9]
+    const float* b1;       // [Cin] or null
 };
 
 // LDS: four planes of 128 rows x 128 bytes (64 bf16): A_hi | A_lo | B_hi | B_lo.  16-byte slot s of row r lives at
@@ -231,7 +236,9 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
 // LDS: A_hi | A_lo windows of `wrows` x 128 B, then B_hi | B_lo tiles of 128 x 128 B.
 constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 511) / 512;
 
-template <bool SPLIT, bool DBUF>
+// C1: the input activations are produced on the fly by a one-input-channel conv3x3+bias+ReLU over `mel` (conv11 fused
+// into conv12: its 786 MB output never exists in HBM).
+template <bool SPLIT, bool DBUF, bool C1>
 __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -296,6 +303,58 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             }
         }
     };
+    // C1: compute this thread's window chunks from the one-channel input and park them directly (no big register
+    // batch: the nine mel taps are L1/L2 hits).  The thread's four channels are the same for all its chunks.
+    auto stage_window_c1 = [&](int c0) {
+        const int ach = tid & 15;
+        float wr[4][9];
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wr[c][t] = p.w1[(size_t)(c0 + ach * 4 + c) * 9 + t];
+            if (p.b1 != nullptr) bv[c] = p.b1[c0 + ach * 4 + c];
+        }
+        // window row of chunk k is (tid >> 4) + 32 k; track (h, w) of its pixel incrementally
+        long long pix = wbase + (tid >> 4);
+        int w_ = 0, h_ = 0;
+        if (pix >= 0) { w_ = (int)(pix % W); h_ = (int)((pix / W) % H); }
+#pragma unroll 2
+        for (int k = 0; k < WACH; ++k) {
+            const int q = tid + 512 * k;
+            if (q < wchunks) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (pix >= 0 && pix < p.M) {
+                    float in[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                        in[t] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? p.mel[pix + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                    }
+                    v = bv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) v[c] = fmaf(in[t], wr[c][t], v[c]);
+                    v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                uint32_t h0, l0, h1, l1;
+                split2(v[0], v[1], h0, l0);
+                split2(v[2], v[3], h1, l1);
+                const int o = lds_off(q >> 4, ach >> 1) + (ach & 1) * 8;
+                *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
+                if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
+            }
+            if (pix >= 0) {
+                w_ += 32;
+                while (w_ >= W) { w_ -= W; if (++h_ == H) h_ = 0; }
+                pix += 32;
+            } else {
+                pix += 32;
+                if (pix >= 0) { w_ = (int)(pix % W); h_ = (int)((pix / W) % H); }
+            }
+        }
+    };
     // B staging: 128 rows x 8 chunks per plane = 1024 chunks; thread handles chunk tid and tid + 512
     u32x4 rbh[2], rbl[2];
     auto load_b = [&](int tap, int c0) {
@@ -328,9 +387,10 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     int it = 0;
     for (int sl = 0; sl < nslab; ++sl) {
         const int c0 = sl * CBK;
-        load_window(c0);
+        if (!C1) load_window(c0);
         if (DBUF && sl > 0) __syncthreads();   // every wave is done reading the previous slab's window
-        store_window();
+        if (C1) stage_window_c1(c0);
+        else store_window();
         for (int tap = 0; tap < 9; ++tap, ++it) {
             // DBUF: the buffer written now was last read two iterations ago, and every wave passed the barrier of
             // the previous iteration only after finishing that read -> ONE barrier per tap.
@@ -413,9 +473,11 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
     return (int)hipGetLastError();
 }
 
-int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
-                                int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
-    if (x == nullptr || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
+static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
+                          const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                          dasv_stream_t stream) {
+    if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
+    if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0 || H > 32767 || W > 65535) return DASV_E_SHAPE;
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
@@ -423,11 +485,12 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
     dasv::ConvParams p;
     p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
+    p.mel = mel; p.w1 = w1; p.b1 = b1;
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
     static int force_tile_kernel = -1;
     if (force_tile_kernel < 0) force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;
-    if (W <= 80 && !force_tile_kernel) {
+    if (W <= 80 && (!force_tile_kernel || mel != nullptr)) {
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
@@ -435,17 +498,22 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
         const bool dbuf = mode == 0 && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
         const size_t lds = lds1 + (dbuf ? 32768 : 0);
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(512);
-#define DASV_LAUNCH_WINDOW(SP, DB)                                                                                   \
+#define DASV_LAUNCH_WINDOW(SP, DB, CC)                                                                               \
         do {                                                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (e != hipSuccess) return (int)e;                                                                      \
-            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB>), grid, block, lds, s, p);                        \
+            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC>), grid, block, lds, s, p);                    \
         } while (0)
-        if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true);
-        else if (mode == 0) DASV_LAUNCH_WINDOW(true, false);
-        else if (dbuf) DASV_LAUNCH_WINDOW(false, true);
-        else DASV_LAUNCH_WINDOW(false, false);
+        if (p.mel != nullptr) {
+            if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true, true);
+            else if (mode == 0) DASV_LAUNCH_WINDOW(true, false, true);
+            else if (dbuf) DASV_LAUNCH_WINDOW(false, true, true);
+            else DASV_LAUNCH_WINDOW(false, false, true);
+        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true, false);
+        else if (mode == 0) DASV_LAUNCH_WINDOW(true, false, false);
+        else if (dbuf) DASV_LAUNCH_WINDOW(false, true, false);
+        else DASV_LAUNCH_WINDOW(false, false, false);
 #undef DASV_LAUNCH_WINDOW
         return (int)hipGetLastError();
     }
@@ -474,6 +542,17 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
         hipLaunchKernelGGL(dasv::conv3x3_igemm_kernel<false>, grid, block, lds, s, p);
     }
     return (int)hipGetLastError();
+}
+
+int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, y, B, H, W, Cin, Cout, relu, stream);
+}
+
+int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,
+                                           const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cmid,
+                                           int Cout, dasv_stream_t stream) {
+    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, y, B, H, W, Cmid, Cout, 1, stream);
 }
 
 }  // extern "C"

@@ -143,6 +143,15 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 
+/* Two layers in one launch: y = relu(conv3x3(relu(conv3x3_1ch(mel) + b1)) + bias) — the first block of the VGG front-end
+ * (`F.relu(self.conv12(F.relu(self.conv11(x))))`, CNNs.py:38-39 / 72-73).  The one-channel layer's activations are
+ * computed while the second layer's input window is staged, so its [B,H,W,Cmid] output never exists in HBM.
+ * mel [B,H,W] fp32, w1 [Cmid,1,3,3] (torch layout), b1 [Cmid] or NULL, w_hi/w_lo: packed weights of the second layer
+ * ([Cout][9][Cmid]); Cmid % 64 == 0, Cout % 128 == 0, W <= 80. */
+int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,
+                                           const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cmid,
+                                           int Cout, dasv_stream_t stream);
+
 /* Weight gradient of the same convolution: gw[Cout,Cin,3,3] (torch layout, OVERWRITTEN) from x [B,H,W,Cin] and
  * g [B,H,W,Cout] = gradient w.r.t. the convolution output (ReLU mask applied by the caller), both NHWC fp32.
  * Replaces autograd's weight gradient of `F.relu(self.convXY(x))` (CNNs.py:38-48 / 72-86; loss.backward(), train.py:220).

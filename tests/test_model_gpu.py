@@ -340,3 +340,21 @@ def test_hip_conv3x3_wgrad_vs_fp64(cin, cout, H, W, B):
     assert float((gwb - ref).abs().max()) / scale < 2e-2
     gw2 = conv.conv3x3_wgrad(x, g, "split").cpu().double()
     assert torch.equal(gw, gw2)   # fixed-order reduction: bitwise reproducible
+
+
+def test_fused_first_block_matches_unfused_and_torch():
+    """conv11 fused into conv12's window staging (one launch) vs the two-launch HIP path vs PyTorch-ROCm."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    torch.manual_seed(5)
+    net = VGG4L(1024).to(DEV).eval()
+    x = torch.from_numpy(rnd(61, 3, 53, 80)).to(DEV)
+    with torch.no_grad():
+        net.conv_mode = "torch"
+        ref = net(x)
+        net.conv_mode = "split"
+        assert net.fuse_first_block is False      # default: measured slower than two launches
+        two = net(x)
+        net.fuse_first_block = True
+        one = net(x)
+    assert float((one - two).abs().max() / two.abs().max()) < 1e-5
+    assert float((one - ref).abs().max() / ref.abs().max()) < 5e-5
