@@ -14,8 +14,8 @@ NHWC activations; `conv_mode`:
   "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs under autocast and for narrow layers)
-Under torch.no_grad() conv11 (Cin = 1) and the 2x2 ceil-mode max-pools also run on hand-written HIP kernels
-(csrc/frontend_misc.hip, pure HBM streams); when a graph is being recorded they are PyTorch-ROCm device ops.
+conv11 (Cin = 1) and the 2x2 ceil-mode max-pools run on hand-written HIP streaming kernels too (csrc/frontend_misc.hip),
+forward and backward (arg-max recomputed; one-channel weight/bias gradient as a fixed-order reduction).
 """
 import math
 
@@ -76,20 +76,22 @@ class _VGG(nn.Module):
             packed = self._packed[key] = _hipconv.PackedConvWeights()
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode)
 
-    def _hip_inference(self, x):
-        """All-HIP inference path: no autograd graph is being built and the activations are fp32 on the GPU."""
+    def _hip_front(self, x):
+        """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
+        features themselves do not need a gradient."""
         c11 = self.conv11
-        return (self.conv_mode != "torch" and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+        return (self.conv_mode != "torch" and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
                 and not torch.is_autocast_enabled() and c11.weight.dtype == torch.float32
                 and c11.out_channels % 4 == 0 and 256 % (c11.out_channels // 4) == 0 and c11.out_channels <= 1024)
 
     def forward(self, paddedInputTensor):
         B, T, Fdim = paddedInputTensor.shape
-        hip = self._hip_inference(paddedInputTensor)
+        hip = self._hip_front(paddedInputTensor)
+        grad = torch.is_grad_enabled()
         fused_first = False
         if hip:
             c12 = self.conv12
-            fused_first = (self.fuse_first_block and Fdim <= 80 and c12.weight.dtype == torch.float32
+            fused_first = (self.fuse_first_block and not grad and Fdim <= 80 and c12.weight.dtype == torch.float32
                            and _hipconv.supported(c12.in_channels, c12.out_channels))
             if fused_first:   # conv11 + conv12 in one launch: conv11's activations never reach HBM
                 key = ("conv12", paddedInputTensor.device.index)
@@ -98,6 +100,8 @@ class _VGG(nn.Module):
                     packed = self._packed[key] = _hipconv.PackedConvWeights()
                 h = _hipconv.conv3x3_c1_conv3x3_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias,
                                                           c12.weight, c12.bias, packed, self.conv_mode)
+            elif grad:
+                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias)
             else:
                 h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias)
         else:
@@ -109,7 +113,10 @@ class _VGG(nn.Module):
                 h = self._conv_relu("conv%d1" % blk, h)
             if not (fused_first and blk == 1):
                 h = self._conv_relu("conv%d2" % blk, h)
-            h = _hipconv.maxpool2x2_ceil(h) if hip else F.max_pool2d(h, 2, stride=2, ceil_mode=True)
+            if hip and h.dtype == torch.float32:
+                h = _hipconv.maxpool2x2_ceil_autograd(h) if grad else _hipconv.maxpool2x2_ceil(h)
+            else:
+                h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
         return h.permute(0, 2, 1, 3).reshape(B, h.size(2), h.size(1) * h.size(3))
 

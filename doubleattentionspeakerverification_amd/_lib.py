@@ -38,6 +38,9 @@ SIGNATURES = {
     "dasv_conv3x3_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_debug_last_variant": (ctypes.c_char_p, []),
 }

@@ -10,7 +10,8 @@ import torch
 from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
-           "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu"]
+           "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu",
+           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
 
 MODES = {"split": 0, "bf16": 1}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
@@ -184,3 +185,68 @@ def conv3x3_c1_conv3x3_bias_relu(mel, w1, b1, weight2, bias2, packed=None, mode=
             torch.cuda.current_stream(mel.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc")
     return y
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward (arg-max recomputed)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = maxpool2x2_ceil(x)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C,
+                                                   torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
+        return gx
+
+
+def maxpool2x2_ceil_autograd(x):
+    """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors."""
+    return _MaxPoolFn.apply(x)
+
+
+class _Conv11ReLUFn(torch.autograd.Function):
+    """relu(conv2d(x[:,None], w, b, padding 1)) for x [B,H,W] (no gradient w.r.t. x: x is the input feature map)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = conv3x3_c1_bias_relu(x, weight, bias)
+        ctx.save_for_backward(x.contiguous(), y)
+        ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y = ctx.saved_tensors
+        lib = _lib.load()
+        B, H, W = x.shape
+        cout = y.shape[1]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        nbytes = lib.dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, cout)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_c1_bwd_nhwc(x.data_ptr(), y.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+                                              None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes, B, H, W, cout,
+                                              torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_c1_bwd_nhwc")
+        return None, gw, gb
+
+
+def conv3x3_c1_bias_relu_autograd(x, weight, bias):
+    """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad."""
+    return _Conv11ReLUFn.apply(x, weight, bias)

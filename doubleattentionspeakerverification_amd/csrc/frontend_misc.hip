@@ -67,6 +67,111 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
     }
 }
 
+// backward of the 2x2 ceil-mode max-pool: every input pixel belongs to exactly one window, so the thread that owns a
+// window recomputes its arg-max (row-major scan, strict '>' — the first maximum wins, as ATen's kernel does) and writes
+// all of the window's input gradients: gy to the arg-max, zero elsewhere.  No indices tensor, no atomics, no memset.
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                  float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
+                                                                  long long nvec) {
+    const int cq = C >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const long long op = i / cq;
+        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
+        const long long b = op / ((long long)Wo * Ho);
+        const int h0 = 2 * ho, w0 = 2 * wo;
+        const size_t base = (((size_t)b * H + h0) * W + w0) * C + q * 4;
+        const bool hw = w0 + 1 < W, hh = h0 + 1 < H;
+        const size_t o1 = base + C, o2 = base + (size_t)W * C, o3 = o2 + C;
+        const f4 v0 = *reinterpret_cast<const f4*>(x + base);
+        const f4 g = *reinterpret_cast<const f4*>(gy + (size_t)op * C + q * 4);
+        f4 m = v0;
+        int arg[4] = {0, 0, 0, 0};
+        f4 v1, v2, v3;
+        if (hw) { v1 = *reinterpret_cast<const f4*>(x + o1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (v1[c] > m[c] || v1[c] != v1[c]) { m[c] = v1[c]; arg[c] = 1; } }
+        if (hh) { v2 = *reinterpret_cast<const f4*>(x + o2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (v2[c] > m[c] || v2[c] != v2[c]) { m[c] = v2[c]; arg[c] = 2; } }
+        if (hw && hh) { v3 = *reinterpret_cast<const f4*>(x + o3);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (v3[c] > m[c] || v3[c] != v3[c]) { m[c] = v3[c]; arg[c] = 3; } }
+        f4 r0, r1, r2, r3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r0[c] = arg[c] == 0 ? g[c] : 0.f; r1[c] = arg[c] == 1 ? g[c] : 0.f;
+            r2[c] = arg[c] == 2 ? g[c] : 0.f; r3[c] = arg[c] == 3 ? g[c] : 0.f;
+        }
+        *reinterpret_cast<f4*>(gx + base) = r0;
+        if (hw) *reinterpret_cast<f4*>(gx + o1) = r1;
+        if (hh) *reinterpret_cast<f4*>(gx + o2) = r2;
+        if (hw && hh) *reinterpret_cast<f4*>(gx + o3) = r3;
+    }
+}
+
+// backward of the one-input-channel conv3x3 + bias + ReLU: gw[n][tap] = sum_pix g[pix][n] * x[pix + tap], gb[n] = sum g,
+// with g = gy * (y > 0).  A pure HBM read stream of gy and y: each workgroup reduces a pixel range into 10 values per
+// channel (registers -> LDS -> one partial row), a second launch adds the rows in a fixed order.
+// part: [nblk][Cout][10]
+__global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ gy, float* __restrict__ part,
+                                                             int H, int W, int Cout, long long npix, int pix_per_block) {
+    extern __shared__ float red[];   // [ppb][Cout][10]
+    const int quads = Cout >> 2, ppb = blockDim.x / quads;
+    const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
+    float acc[4][10];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) acc[c][t] = 0.f;
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    const long long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    if (pl < ppb) {
+        for (long long pix = p0 + pl; pix < p1; pix += ppb) {
+            const int w_ = (int)(pix % W), h_ = (int)((pix / W) % H);
+            const f4 yy = *reinterpret_cast<const f4*>(y + (size_t)pix * Cout + q * 4);
+            f4 g = *reinterpret_cast<const f4*>(gy + (size_t)pix * Cout + q * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[c] = yy[c] > 0.f ? g[c] : 0.f;
+            float in[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                in[t] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? x[pix + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(g[c], in[t], acc[c][t]);
+                acc[c][9] += g[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 10; ++t) red[((size_t)pl * Cout + q * 4 + c) * 10 + t] = acc[c][t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * 10; i += blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ppb; ++k) v += red[(size_t)k * Cout * 10 + i];
+        part[(size_t)blockIdx.x * Cout * 10 + i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __restrict__ part, float* __restrict__ gw,
+                                                             float* __restrict__ gb, int nblk, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, t) with t in 0..9
+    if (i >= Cout * 10) return;
+    float v = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < nblk; ++k) v += part[(size_t)k * Cout * 10 + i];
+    const int n = i / 10, t = i - n * 10;
+    if (t < 9) gw[n * 9 + t] = v;
+    else if (gb != nullptr) gb[n] = v;
+}
+
 }  // namespace dasv
 
 extern "C" {
@@ -92,6 +197,45 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo, nvec);
+    return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream) {
+    if (x == nullptr || gy == nullptr || gx == nullptr) return DASV_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long nvec = (long long)B * Ho * Wo * (C / 4);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
+                       C, Ho, Wo, nvec);
+    return (int)hipGetLastError();
+}
+
+size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return (size_t)2048 * Cout * 10 * sizeof(float);
+}
+
+int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream) {
+    if (x == nullptr || y == nullptr || gy == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
+    if (workspace_bytes < dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, Cout)) return DASV_E_WORKSPACE;
+    const long long npix = (long long)B * H * W;
+    const int ppb = 256 / (Cout / 4);
+    int nblk = (int)((npix + ppb - 1) / ppb < 2048 ? (npix + ppb - 1) / ppb : 2048);
+    const int pix_per_block = (int)((npix + nblk - 1) / nblk);
+    nblk = (int)((npix + pix_per_block - 1) / pix_per_block);
+    const size_t lds = (size_t)ppb * Cout * 10 * sizeof(float);
+    if (lds > 64 * 1024) return DASV_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_kernel, dim3((unsigned)nblk), dim3(256), lds, s, x, y, gy, part, H, W, Cout, npix,
+                       pix_per_block);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 + 255) / 256)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
     return (int)hipGetLastError();
 }
 

@@ -169,6 +169,17 @@ int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* 
  * `F.max_pool2d(x, 2, stride=2, ceil_mode=True)` (CNNs.py:40,44,48 / 74,78,82,86).  C % 4 == 0. */
 int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream);
 
+/* Backward of the max-pool above: gx [B,H,W,C] (OVERWRITTEN) from x [B,H,W,C] and gy [B,ceil(H/2),ceil(W/2),C]; the
+ * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d
+ * backward for CNNs.py:40,44,48 / 74,78,82,86. */
+int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream);
+/* Backward of the one-input-channel layer: from x [B,H,W], its output y [B,H,W,Cout] and gy (gradient w.r.t. y, before
+ * the ReLU mask): gw [Cout,1,3,3] and gb [Cout] (or NULL), both OVERWRITTEN; fixed-order reduction.  Replaces autograd's
+ * backward of `F.relu(self.conv11(x))` (CNNs.py:38 / 72).  workspace: dasv_conv3x3_c1_bwd_workspace_bytes(). */
+size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout);
+int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts

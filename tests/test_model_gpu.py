@@ -358,3 +358,30 @@ def test_fused_first_block_matches_unfused_and_torch():
         one = net(x)
     assert float((one - two).abs().max() / two.abs().max()) < 1e-5
     assert float((one - ref).abs().max() / ref.abs().max()) < 5e-5
+
+
+def test_hip_maxpool_and_conv11_backward_match_torch():
+    from doubleattentionspeakerverification_amd import conv
+    # max-pool: ReLU-like inputs full of ties (zeros) — the arg-max choice must be ATen's (first maximum wins)
+    for shape in ((2, 64, 37, 80), (3, 32, 19, 5), (1, 16, 1, 1), (2, 128, 10, 3)):
+        x = torch.relu(torch.from_numpy(rnd(71, *shape))).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        x2 = x.detach().clone().requires_grad_(True)
+        y = conv.maxpool2x2_ceil_autograd(x)
+        yr = torch.nn.functional.max_pool2d(x2, 2, stride=2, ceil_mode=True)
+        gy = torch.from_numpy(rnd(72, *yr.shape)).to(DEV)
+        (y * gy).sum().backward()
+        (yr * gy).sum().backward()
+        assert torch.equal(y, yr) and torch.equal(x.grad, x2.grad)
+    # first layer
+    x = torch.from_numpy(rnd(73, 3, 41, 80)).to(DEV)
+    w = torch.from_numpy(rnd(74, 128, 1, 3, 3, scale=0.3)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rnd(75, 128, scale=0.1)).to(DEV).requires_grad_(True)
+    gy = torch.from_numpy(rnd(76, 3, 128, 41, 80)).to(DEV)
+    y = conv.conv3x3_c1_bias_relu_autograd(x, w, b)
+    (y * gy).sum().backward()
+    g1 = (w.grad.clone(), b.grad.clone())
+    w.grad = b.grad = None
+    yr = torch.relu(torch.nn.functional.conv2d(x.unsqueeze(1), w, b, padding=1))
+    (yr * gy).sum().backward()
+    np.testing.assert_allclose(g1[0].cpu().numpy(), w.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()))
+    np.testing.assert_allclose(g1[1].cpu().numpy(), b.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()))
