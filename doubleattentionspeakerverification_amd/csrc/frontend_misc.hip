@@ -214,7 +214,7 @@ int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, in
 
 size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-    return (size_t)2048 * Cout * 10 * sizeof(float);
+    return (size_t)512 * Cout * 10 * sizeof(float);
 }
 
 int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
@@ -224,7 +224,7 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
     if (workspace_bytes < dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, Cout)) return DASV_E_WORKSPACE;
     const long long npix = (long long)B * H * W;
     const int ppb = 256 / (Cout / 4);
-    int nblk = (int)((npix + ppb - 1) / ppb < 2048 ? (npix + ppb - 1) / ppb : 2048);
+    int nblk = (int)((npix + ppb - 1) / ppb < 512 ? (npix + ppb - 1) / ppb : 512);   // few partial rows: the second launch is serial in them
     const int pix_per_block = (int)((npix + nblk - 1) / nblk);
     nblk = (int)((npix + pix_per_block - 1) / pix_per_block);
     const size_t lds = (size_t)ppb * Cout * 10 * sizeof(float);
