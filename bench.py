@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--conv", default="split", choices=["split", "bf16", "torch"],
+    ap.add_argument("--conv", default="split", choices=["split", "bf16", "fp16", "torch"],
                     help="front-end convolutions: hand-written MFMA implicit GEMM with split-bf16 operands (fp32-grade, "
                          "default) or bf16 operands, or PyTorch-ROCm/MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,7 +266,8 @@ def main():
                       "global_batch": B * world, "frames": T, "parallelism": "replicas x%d (no data exchange)" % world,
                       "conv": {"split": "hand-written MFMA implicit GEMM, fp32 operands split into bf16 hi+lo (3 MFMAs per "
                                         "product, fp32 accumulate; ~5e-6 relative error vs fp32 conv)",
-                               "bf16": "hand-written MFMA implicit GEMM, bf16 operands", "torch": "PyTorch-ROCm / MIOpen"}[args.conv]
+                               "bf16": "hand-written MFMA implicit GEMM, bf16 operands",
+                               "fp16": "hand-written MFMA implicit GEMM, fp16 operands (fp32 accumulate)", "torch": "PyTorch-ROCm / MIOpen"}[args.conv]
                               if compute_dtype == torch.float32 else "PyTorch-ROCm / MIOpen under bf16 autocast"}
         else:
             from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
@@ -341,7 +342,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if compute_dtype == torch.float32 else "bf16",
+            "dtype": ("f32" if args.workload == "pool" or args.conv in ("split", "torch") else args.conv)
+                     if compute_dtype == torch.float32 else "bf16",
             "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
             "config": config, "roofline": roofline, "roofline_pooling": pool_roof, "cpu_baseline": cpu,
         }

@@ -13,6 +13,7 @@ kernel sizes) run on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU`
 NHWC activations; `conv_mode`:
   "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
   "bf16"   operands rounded to bf16 (one MFMA per product)
+  "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
   "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs under autocast and for narrow layers)
 conv11 (Cin = 1) and the 2x2 ceil-mode max-pools run on hand-written HIP streaming kernels too (csrc/frontend_misc.hip),
 forward and backward (arg-max recomputed; one-channel weight/bias gradient as a fixed-order reduction).

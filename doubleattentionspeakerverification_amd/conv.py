@@ -3,7 +3,9 @@ replaces `F.relu(self.convXY(x))` of the reference's CNNs.py:38-48 / 72-86 for t
 
 Activations stay fp32 in NHWC memory (torch `channels_last` tensors are passed zero-copy).  mode "split" keeps fp32
 accuracy on the bf16 matrix cores (operands split hi + lo, three MFMAs per product); mode "bf16" rounds operands to
-bf16.  Backward (training) goes through ATen's convolution_backward on the saved tensors.
+bf16, mode "fp16" to fp16 (11 mantissa bits, forward only: its gradients run with bf16 operands, whose exponent range
+covers small gradients).  Backward: data gradient = the same kernel with transposed, flipped weights; weight gradient =
+csrc/conv3x3_wgrad.hip.
 """
 import torch
 
@@ -13,7 +15,8 @@ __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bi
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu",
            "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
 
-MODES = {"split": 0, "bf16": 1}
+MODES = {"split": 0, "bf16": 1, "fp16": 2}
+BACKWARD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16"}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
 
 
@@ -28,8 +31,9 @@ class PackedConvWeights:
         self.key = None
         self.hi = self.lo = None
 
-    def get(self, weight):
-        key = (weight.data_ptr(), weight._version, weight.device)
+    def get(self, weight, mode="split"):
+        f16 = mode == "fp16"
+        key = (weight.data_ptr(), weight._version, weight.device, f16)
         if key != self.key:
             lib = _lib.load()
             cout, cin = weight.shape[0], weight.shape[1]
@@ -39,8 +43,11 @@ class PackedConvWeights:
                 self.hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
                 self.lo = torch.empty(n, dtype=torch.uint8, device=weight.device)
             with torch.cuda.device(weight.device):
-                rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin,
-                                                   torch.cuda.current_stream(weight.device).cuda_stream)
+                stream = torch.cuda.current_stream(weight.device).cuda_stream
+                if f16:
+                    rc = lib.dasv_conv3x3_pack_weights_f16(w.data_ptr(), self.hi.data_ptr(), cout, cin, stream)
+                else:
+                    rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)
             _lib.check(rc, "dasv_conv3x3_pack_weights")
             self.key = key
         return self.hi, self.lo
@@ -85,7 +92,7 @@ def conv3x3_wgrad(x, g, mode="split"):
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mode):
-        hi, lo = packed.get(weight)
+        hi, lo = packed.get(weight, mode)
         y = _launch(x, hi, lo, bias, weight.shape[0], mode)
         ctx.save_for_backward(x, weight, y)
         ctx.has_bias = bias is not None
@@ -99,6 +106,7 @@ class _ConvReLUFn(torch.autograd.Function):
         g = torch.ops.aten.threshold_backward(gy.contiguous(memory_format=torch.channels_last), y, 0.0)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = None
+        bmode = BACKWARD_MODE[ctx.mode]
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if want_x and supported(cout, cin) and g.dtype == torch.float32:
@@ -106,12 +114,12 @@ class _ConvReLUFn(torch.autograd.Function):
             # transposed over (Cout, Cin) and flipped over (ky, kx): reuse the forward implicit-GEMM kernel
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
             pk = PackedConvWeights()
-            hi, lo = pk.get(wt)
-            gx = _launch(g, hi, lo, None, cin, ctx.mode, relu=0)
+            hi, lo = pk.get(wt, bmode)
+            gx = _launch(g, hi, lo, None, cin, bmode, relu=0)
             want_x = False
         gw = gb = None
         if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3]) and g.dtype == torch.float32:
-            gw = conv3x3_wgrad(x, g, ctx.mode)
+            gw = conv3x3_wgrad(x, g, bmode)
             want_w = False
             if want_b:
                 gb = g.sum(dim=(0, 2, 3))
@@ -175,7 +183,7 @@ def conv3x3_c1_conv3x3_bias_relu(mel, w1, b1, weight2, bias2, packed=None, mode=
     B, H, W = mel.shape
     cmid, cout = weight2.shape[1], weight2.shape[0]
     packed = packed or PackedConvWeights()
-    hi, lo = packed.get(weight2)
+    hi, lo = packed.get(weight2, mode)
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=mel.device, memory_format=torch.channels_last)
     with torch.cuda.device(mel.device):
         rc = lib.dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(

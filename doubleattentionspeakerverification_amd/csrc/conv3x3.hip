@@ -11,7 +11,9 @@
 //     is accumulated as hi*hi + hi*lo + lo*hi in fp32 on v_mfma_f32_16x16x32_bf16 (three MFMAs per product,
 //     dropping lo*lo ~ 2^-18): ~2^-16 relative error per product, i.e. fp32-grade for the 1e-3 embedding bar,
 //     at a third of the bf16 MFMA rate — which is still ~5x the fp32 MFMA rate.
-//   BF16: hi only (one MFMA per product).
+//   BF16: hi only (one MFMA per product), 8 mantissa bits.
+//   F16:  operands rounded to fp16 (11 mantissa bits, v_mfma_f32_16x16x32_f16), one MFMA per product; activations
+//     beyond +-65504 overflow, so this is a forward/inference mode (weights come from dasv_conv3x3_pack_weights_f16).
 // Tile: 128 pixels x 128 channels x 64 (one tap's channel slab) per 256-thread workgroup; 2x2 waves, each
 // 64x64 = 4x4 MFMA tiles.  Global -> registers (next K-step, issued before the MFMAs of the current one) ->
 // LDS (XOR-swizzled 16-byte slots so ds_read_b128 fragment reads spread over the banks) -> MFMA.
@@ -41,6 +43,39 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     const bf16x2_t l = __builtin_convertvector(v - hf, bf16x2_t);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// precision of the MFMA operands: split-bf16 (three products), bf16, fp16
+constexpr int PREC_SPLIT = 0, PREC_BF16 = 1, PREC_F16 = 2;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// staging conversion of two fp32 values: `hi` gets the packed 16-bit operands of the mode, `lo` the split residuals
+template <int PREC>
+__device__ __forceinline__ void cvt2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    if (PREC == PREC_F16) {
+        const f32x2_t v = {a, b};
+        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));   // RNE; |v| > 65504 becomes inf
+        lo = 0;
+    } else {
+        split2(a, b, hi, lo);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (PREC == PREC_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// weights [Cout][Cin][3][3] fp32 (torch) -> fp16 plane [Cout][9][Cin]
+__global__ void conv3x3_pack_weights_f16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wh, int Cout, int Cin) {
+    const long long n = (long long)Cout * 9 * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin);
+        const int tap = (int)((i / Cin) % 9);
+        const int o = (int)(i / ((long long)Cin * 9));
+        wh[i] = __builtin_bit_cast(uint16_t, (_Float16)w[((long long)o * Cin + c) * 9 + tap]);
+    }
 }
 
 // weights [Cout][Cin][3][3] fp32 (torch) -> hi/lo planes [Cout][9][Cin] bf16
@@ -79,8 +114,9 @@ struct ConvParams {
 // r*128 + ((s ^ (r & 7)) * 16).
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
-template <bool SPLIT>
+template <int PREC>
 __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) {
+    constexpr bool SPLIT = PREC == PREC_SPLIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ahi = smem;
     char* Alo = smem + 16384;
@@ -148,8 +184,8 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
         for (int i = 0; i < 8; ++i) {
             const int row = arow0 + 16 * i;
             uint32_t h0, l0, h1, l1;
-            split2(ra[i][0], ra[i][1], h0, l0);
-            split2(ra[i][2], ra[i][3], h1, l1);
+            cvt2<PREC>(ra[i][0], ra[i][1], h0, l0);
+            cvt2<PREC>(ra[i][2], ra[i][3], h1, l1);
             const int o = lds_off(row, ach >> 1) + (ach & 1) * 8;
             *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
             if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
@@ -194,7 +230,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
                 if (SPLIT) al = *reinterpret_cast<const bf16x8*>(Alo + o);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<PREC>(ah, bh[j], acc[i][j]);
                     if (SPLIT) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
@@ -238,8 +274,9 @@ constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 51
 
 // C1: the input activations are produced on the fly by a one-input-channel conv3x3+bias+ReLU over `mel` (conv11 fused
 // into conv12: its 786 MB output never exists in HBM).
-template <bool SPLIT, bool DBUF, bool C1>
+template <int PREC, bool DBUF, bool C1>
 __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p) {
+    constexpr bool SPLIT = PREC == PREC_SPLIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int W = p.W, H = p.H, Cin = p.Cin;
@@ -295,8 +332,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             if (q < wchunks) {
                 const int row = q >> 4, ach = q & 15;
                 uint32_t h0, l0, h1, l1;
-                split2(ra[k][0], ra[k][1], h0, l0);
-                split2(ra[k][2], ra[k][3], h1, l1);
+                cvt2<PREC>(ra[k][0], ra[k][1], h0, l0);
+                cvt2<PREC>(ra[k][2], ra[k][3], h1, l1);
                 const int o = lds_off(row, ach >> 1) + (ach & 1) * 8;
                 *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
                 if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
@@ -339,8 +376,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                     v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
                 }
                 uint32_t h0, l0, h1, l1;
-                split2(v[0], v[1], h0, l0);
-                split2(v[2], v[3], h1, l1);
+                cvt2<PREC>(v[0], v[1], h0, l0);
+                cvt2<PREC>(v[2], v[3], h1, l1);
                 const int o = lds_off(q >> 4, ach >> 1) + (ach & 1) * 8;
                 *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
                 if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
@@ -424,7 +461,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                     for (int j = 0; j < 4; ++j) {
                         // weights as the A operand, pixels as B: the 16x16 result has channels on its rows, so a
                         // lane ends up with 4 consecutive channels of one pixel (16-byte stores in the epilogue)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<PREC>(bh[j], ah, acc[i][j]);
                         if (SPLIT) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
@@ -473,6 +510,16 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
     return (int)hipGetLastError();
 }
 
+int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream) {
+    if (w == nullptr || w_f16 == nullptr) return DASV_E_NULL;
+    if (Cout <= 0 || Cin <= 0) return DASV_E_SHAPE;
+    const long long n = (long long)Cout * 9 * Cin;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<uint16_t*>(w_f16), Cout, Cin);
+    return (int)hipGetLastError();
+}
+
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu,
                           dasv_stream_t stream) {
@@ -481,7 +528,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0 || H > 32767 || W > 65535) return DASV_E_SHAPE;
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
-    if (mode != 0 && mode != 1) return DASV_E_DTYPE;
+    if (mode < 0 || mode > 2) return DASV_E_DTYPE;
     dasv::ConvParams p;
     p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
@@ -506,14 +553,14 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC>), grid, block, lds, s, p);                    \
         } while (0)
         if (p.mel != nullptr) {
-            if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true, true);
-            else if (mode == 0) DASV_LAUNCH_WINDOW(true, false, true);
-            else if (dbuf) DASV_LAUNCH_WINDOW(false, true, true);
-            else DASV_LAUNCH_WINDOW(false, false, true);
-        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(true, true, false);
-        else if (mode == 0) DASV_LAUNCH_WINDOW(true, false, false);
-        else if (dbuf) DASV_LAUNCH_WINDOW(false, true, false);
-        else DASV_LAUNCH_WINDOW(false, false, false);
+            if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, true);
+            else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true);
+            else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true);
+            else DASV_LAUNCH_WINDOW(2, false, true);
+        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false);
+        else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false);
+        else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false);
+        else DASV_LAUNCH_WINDOW(2, false, false);
 #undef DASV_LAUNCH_WINDOW
         return (int)hipGetLastError();
     }
@@ -522,25 +569,17 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.tiles_per_xcd = (tiles + 7) / 8;
     const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(256);
     const size_t lds = 65536;
-    if (mode == 0) {
-        static bool attr0 = false;
-        if (!attr0) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_igemm_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            attr0 = true;
-        }
-        hipLaunchKernelGGL(dasv::conv3x3_igemm_kernel<true>, grid, block, lds, s, p);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_igemm_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(dasv::conv3x3_igemm_kernel<false>, grid, block, lds, s, p);
-    }
+#define DASV_LAUNCH_TILE(PR)                                                                                        \
+    do {                                                                                                            \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_igemm_kernel<PR>),           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL(dasv::conv3x3_igemm_kernel<PR>, grid, block, lds, s, p);                                  \
+    } while (0)
+    if (mode == 0) DASV_LAUNCH_TILE(0);
+    else if (mode == 1) DASV_LAUNCH_TILE(1);
+    else DASV_LAUNCH_TILE(2);
+#undef DASV_LAUNCH_TILE
     return (int)hipGetLastError();
 }
 

@@ -137,9 +137,13 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
  *       mode 0: split-bf16 operands (x = hi + lo, three MFMAs per product, fp32 accumulate): ~2^-16 relative error
  *               per product, fp32-grade for this model's 1e-3 embedding bar.
  *       mode 1: plain bf16 operands (one MFMA per product).
+ *       mode 2: fp16 operands (one MFMA per product, 11 mantissa bits; |activation| must stay below 65504): w_hi is the
+ *               plane written by dasv_conv3x3_pack_weights_f16, w_lo is ignored (the "fp16 MFMA path" of BASELINE
+ *               config 5 — forward only; gradients go through mode 0 or 1).
  * ------------------------------------------------------------------------ */
 size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin);
 int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, dasv_stream_t stream);
+int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 

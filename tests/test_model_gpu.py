@@ -215,9 +215,11 @@ def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
     with torch.no_grad():
         ys = conv.conv3x3_bias_relu(x, w, b, None, "split").cpu().double()
         yb = conv.conv3x3_bias_relu(x, w, b, None, "bf16").cpu().double()
+        yh = conv.conv3x3_bias_relu(x, w, b, None, "fp16").cpu().double()
     assert ys.shape == ref.shape
     assert float((ys - ref).abs().max()) / scale < 2e-5
     assert float((yb - ref).abs().max()) / scale < 1e-2
+    assert float((yh - ref).abs().max()) / scale < 1.25e-3   # fp16 operands: 8x tighter than bf16
 
 
 def test_hip_conv_backward_matches_torch_autograd():
@@ -277,11 +279,50 @@ def test_frontend_hip_path_equals_torch_path_on_default_width():
         y = net(x)
         net.conv_mode = "bf16"
         yb = net(x)
+        net.conv_mode = "fp16"
+        yh = net(x)
     assert y.shape == ref.shape == (2, 5, 5120)
     rel = float((y - ref).abs().max() / ref.abs().max())
     relb = float((yb - ref).abs().max() / ref.abs().max())
-    print("front-end output: split-vs-torch rel err %.2e, bf16-vs-torch %.2e" % (rel, relb))
-    assert rel < 5e-5 and relb < 3e-2
+    relh = float((yh - ref).abs().max() / ref.abs().max())
+    print("front-end output: split-vs-torch rel err %.2e, bf16-vs-torch %.2e, fp16-vs-torch %.2e" % (rel, relb, relh))
+    assert rel < 5e-5 and relb < 3e-2 and relh < 4e-3
+
+
+def test_fp16_mfma_mode_embedding_error_and_training_step():
+    """BASELINE config 5's "fp16 MFMA path": conv operands rounded to fp16 (fp32 accumulate, fp32 activations in HBM).
+    The embedding error against the fp32-grade path is stated, and a training step runs (gradients: bf16 operands)."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=100, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(7)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).eval()
+    x = torch.from_numpy(rnd(51, 3, 150, 80)).to(DEV)
+    with torch.no_grad():
+        ref = net.getEmbedding(x)
+        net.front_end.conv_mode = "fp16"
+        emb = net.getEmbedding(x)
+        net.front_end.conv_mode = "bf16"
+        embb = net.getEmbedding(x)
+    rel = float((emb - ref).abs().max() / ref.abs().max())
+    relb = float((embb - ref).abs().max() / ref.abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("fp16-operand front-end: embedding rel err %.3e vs split mode (cos %.7f); bf16 operands %.3e" % (rel, cos, relb))
+    assert rel < 1e-3 and 1 - cos < 1e-4 and relb < 1e-2
+    net.train()
+    y = torch.tensor([1, 5, 7], device=DEV)
+    grads = {}
+    for mode in ("fp16", "split"):
+        net.front_end.conv_mode = mode
+        net.zero_grad()
+        torch.manual_seed(11)                      # same train-time head mask in both runs
+        pred, _ = net(x, label=y, step=0)
+        torch.nn.functional.cross_entropy(pred, y).backward()
+        grads[mode] = torch.cat([net.front_end.conv32.weight.grad.flatten(), net.front_end.conv12.weight.grad.flatten()]).clone()
+    assert torch.isfinite(grads["fp16"]).all()
+    gcos = float(torch.nn.functional.cosine_similarity(grads["fp16"], grads["split"], dim=0))
+    print("fp16-mode conv weight gradients vs split mode: cosine %.5f" % gcos)
+    assert gcos > 0.995
 
 
 def test_data_parallel_trainer_single_rank_matches_plain_optimizer_step():
