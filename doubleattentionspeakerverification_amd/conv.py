@@ -65,8 +65,10 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1):
     return y
 
 
-def supported_wgrad(cin, cout, width=1):
-    return cin % 64 == 0 and cout % 64 == 0 and width <= 80
+def supported_wgrad(cin, cout, width=1, pixels=0):
+    """Shapes the weight-gradient kernel takes: 64-channel tiles, maps up to 80 columns, operands below 4 GB
+    (`pixels` = B*H*W; the kernel addresses them through 32-bit buffer offsets)."""
+    return cin % 64 == 0 and cout % 64 == 0 and width <= 80 and pixels * max(cin, cout) * 4 < 0xffffffff
 
 
 def conv3x3_wgrad(x, g, mode="split"):
@@ -118,7 +120,7 @@ class _ConvReLUFn(torch.autograd.Function):
             gx = _launch(g, hi, lo, None, cin, bmode, relu=0)
             want_x = False
         gw = gb = None
-        if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3]) and g.dtype == torch.float32:
+        if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
             gw = conv3x3_wgrad(x, g, bmode)
             want_w = False
             if want_b:

@@ -28,6 +28,12 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int WKC = 64;   // pixels per K chunk
 
+// timing experiments only (tools/wgrad_diag.py builds this file with -DDASV_WGRAD_DIAG=n; results are wrong then):
+// 1 = stage only the first two chunks, 2 = no MFMA section
+#ifndef DASV_WGRAD_DIAG
+#define DASV_WGRAD_DIAG 0
+#endif
+
 __device__ __forceinline__ void wsplit2(float a, float b, uint32_t& hi, uint32_t& lo) {
     const f32x2_t v = {a, b};
     const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
@@ -48,6 +54,8 @@ struct WgradParams {
     int chunks_per_split;
     int S;
     int xrows;          // rows of the padded x window image in LDS
+    int magic_w;        // floor(65536 / W) + 1: (v * magic_w) >> 16 == v / W for v * W < 65536
+    int hcarries;       // image-row carries a 16-position step of the window walk can cause: ceil((16/(W+1) + 1) / (H+1))
 };
 
 __host__ __device__ inline int wgrad_xrows(int W) { return WKC + WKC / W + 2 + 2 * (W + 2) + 1; }
@@ -65,120 +73,159 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-// NX: x-window rows a thread stages per chunk (ceil(xrows / 16)); the next chunk's g and x are fetched into registers
-// before the MFMA section of the current one and written to LDS after it, so HBM/L2 latency hides behind the MFMAs.
+// One LDS buffer: G_hi | G_lo ([WKC][64] bf16) | X_hi | X_lo ([16 * NX][64] bf16, zero-padded image coordinates; the
+// window's `xrows` rows rounded up to what the 16 staging rows per step cover) | Ltab[WKC]
+__host__ __device__ constexpr size_t wgrad_buffer_bytes(int nx) {
+    return 2 * (size_t)WKC * 128 + 2 * (size_t)(16 * nx) * 128 + WKC * sizeof(int);
+}
+
+// Workgroup = 8 waves with two roles (the accumulators alone take 144 registers, so a SIMD holds two such waves at most;
+// two copies of one program in lock step between barriers would leave the matrix cores idle while both stage):
+//   waves 0-3 (one per SIMD)  CONSUMERS: MFMAs only, out of the LDS buffer of the current chunk;
+//   waves 4-7 (one per SIMD)  PRODUCERS: fetch chunk i+2 from global memory, split chunk i+1 and park it in the other
+//                             LDS buffer — their VALU/memory work runs in the issue slots the partner's MFMAs leave free.
+// One barrier per chunk swaps the buffers.  NX: x-window rows a producer thread stages per chunk (ceil(xrows / 16)).
 template <bool SPLIT, int NX>
-__global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, H = p.H, Cin = p.Cin, Cout = p.Cout;
     const int HW = H * W;
-    char* Ghi = smem;                        // [WKC][64] bf16
-    char* Glo = Ghi + WKC * 128;
-    char* Xhi = Glo + WKC * 128;             // [xrows][64] bf16, zero-padded image coordinates
-    char* Xlo = Xhi + (size_t)p.xrows * 128;
-    int* Ltab = reinterpret_cast<int*>(Xlo + (size_t)p.xrows * 128);   // [WKC] window row of each chunk pixel (tap 0,0)
+    constexpr size_t bufsz = wgrad_buffer_bytes(NX);
+    constexpr size_t xplane = (size_t)(16 * NX) * 128;
 
     const int tiles = p.ntiles * p.ctiles;
     const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
     const int n0 = (tile / p.ctiles) * 64, c0 = (tile % p.ctiles) * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;   // wave = input-channel block
-    const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int scc = tid & 15, srow = tid >> 4;                     // staging: 4-channel chunk, first row
+    const int chunk_lo = split * p.chunks_per_split;
+    const int total_chunks = p.B * p.chunks_per_image;
+    const int chunk_hi = min(total_chunks, chunk_lo + p.chunks_per_split);
+    const int nch = chunk_hi - chunk_lo;
+    const int tid = threadIdx.x;
 
+    if (tid >= 256) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - 256;
+        const int scc = ptid & 15, srow = ptid >> 4;   // staging: 4-channel chunk, first row
+        f32x4 gr[4], xr[NX];
+        int w0_next = 0;
+        // issue the global loads of chunk `ch` (rows beyond the utterance / outside the image become zeros).  The
+        // producers share each SIMD's issue slots with a consumer's MFMAs, so the address arithmetic is kept to a few
+        // 32-bit operations per load: per-thread offsets are precomputed and coordinates are carried, never divided.
+        // Loads are raw buffer loads: a lane whose row is outside the utterance / image passes an offset beyond the
+        // buffer and gets zeros from the hardware range check — no branches around the loads.
+        const unsigned g_rowbytes = (unsigned)Cout * 4u, x_rowbytes = (unsigned)Cin * 4u;
+        const unsigned g_bytes = (unsigned)p.B * (unsigned)HW * g_rowbytes, x_bytes = (unsigned)p.B * (unsigned)HW * x_rowbytes;
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, g_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, x_bytes, 0x00020000);
+        const unsigned g_thread = (unsigned)(n0 + scc * 4) * 4u + (unsigned)srow * g_rowbytes;
+        const unsigned x_thread = (unsigned)(c0 + scc * 4) * 4u;
+        const int a16 = 16 / (W + 1), r16 = 16 - a16 * (W + 1);   // 16 padded positions = a16 rows + r16 columns
+        const unsigned step_bytes = (unsigned)(r16 + a16 * W) * x_rowbytes, w_bytes = (unsigned)W * x_rowbytes;
+        auto fetch = [&](int ch) {
+            const int b = ch / p.chunks_per_image;
+            const int off = (ch - b * p.chunks_per_image) * WKC;
+            const int npx = min(WKC, HW - off);
+            const int h0 = off / W, w0 = off - h0 * W;    // wave-uniform: once per chunk
+            w0_next = w0;
+            const unsigned gbase = (unsigned)(b * HW + off) * g_rowbytes + g_thread;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned o = srow + 16 * k < npx ? gbase + (unsigned)(16 * k) * g_rowbytes : g_bytes;
+                gr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)o, 0, 0));
+            }
+            // padded coordinates: image rows have W+1 columns (column W is zero), images H+1 rows (row H is zero).
+            // Window row 0 is the chunk's first pixel moved up one padded row and left one column; this thread starts
+            // `srow` further and then steps by 16 padded positions with carries; positions before the first image
+            // have bq < 0.
+            int bq = b, hq = h0 - 1, wq = w0 - 1 + srow;
+            if (wq < 0) { wq += W + 1; --hq; }
+            while (wq >= W + 1) { wq -= W + 1; ++hq; }
+            if (hq < 0) { hq += H + 1; --bq; }
+            while (hq >= H + 1) { hq -= H + 1; ++bq; }
+            // byte offset of (bq, hq, wq) carried along (mod 2^32; only used where the position is a real pixel): a column
+            // carry skips one pad position, a row carry a pad row
+            unsigned ob = (unsigned)((bq * H + hq) * W + wq) * x_rowbytes + x_thread;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const bool ok = (wq < W) & (hq < H) & ((unsigned)bq < (unsigned)p.B);
+                xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(ok ? ob : x_bytes), 0, 0));
+                wq += r16;
+                const bool cw = wq >= W + 1;
+                wq -= cw ? W + 1 : 0;
+                hq += a16 + (cw ? 1 : 0);
+                unsigned rows_skipped = 0;
+                for (int c = 0; c < p.hcarries; ++c) {      // uniform trip count: 1 unless the map has very few rows
+                    const bool chh = hq >= H + 1;
+                    hq -= chh ? H + 1 : 0;
+                    bq += chh ? 1 : 0;
+                    rows_skipped += chh ? w_bytes : 0u;
+                }
+                ob += step_bytes - (cw ? x_rowbytes : 0u) - rows_skipped;
+            }
+        };
+        // split and park the fetched chunk in LDS buffer `buf`
+        auto park = [&](char* buf) {
+            char* Ghi = buf;
+            char* Glo = Ghi + WKC * 128;
+            char* Xhi = Glo + WKC * 128;
+            char* Xlo = Xhi + xplane;
+            int* Ltab = reinterpret_cast<int*>(Xlo + xplane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t h0_, l0_, h1_, l1_;
+                wsplit2(gr[k][0], gr[k][1], h0_, l0_);
+                wsplit2(gr[k][2], gr[k][3], h1_, l1_);
+                const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                *reinterpret_cast<uint2*>(Ghi + o) = make_uint2(h0_, h1_);
+                if (SPLIT) *reinterpret_cast<uint2*>(Glo + o) = make_uint2(l0_, l1_);
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                uint32_t h0_, l0_, h1_, l1_;
+                wsplit2(xr[k][0], xr[k][1], h0_, l0_);
+                wsplit2(xr[k][2], xr[k][3], h1_, l1_);
+                const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                *reinterpret_cast<uint2*>(Xhi + o) = make_uint2(h0_, h1_);
+                if (SPLIT) *reinterpret_cast<uint2*>(Xlo + o) = make_uint2(l0_, l1_);
+            }
+            // chunk pixel j -> window row (every image-row end crossed adds one pad position)
+            if (ptid < WKC) Ltab[ptid] = ptid + (int)(((unsigned)(w0_next + ptid) * (unsigned)p.magic_w) >> 16) + (W + 2);
+        };
+
+        if (nch > 0) {
+            fetch(chunk_lo);
+            park(smem);
+            if (nch > 1) fetch(chunk_lo + 1);
+        }
+        __syncthreads();
+        for (int i = 0; i < nch; ++i) {
+            if (i + 1 < nch && (DASV_WGRAD_DIAG != 1 || i == 0)) {
+                park(smem + ((i + 1) & 1) * bufsz);
+                if (i + 2 < nch) fetch(chunk_lo + i + 2);     // in flight while the consumers work on chunk i+1
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int lane = tid & 63, wv = tid >> 6;   // wave = input-channel block
+    const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     f32x4 acc[4][9];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int chunk_lo = split * p.chunks_per_split;
-    const int total_chunks = p.B * p.chunks_per_image;
-    const int chunk_hi = min(total_chunks, chunk_lo + p.chunks_per_split);
-
-    f32x4 gr[4], xr[NX];
-    int w0_next = 0;
-    // issue the global loads of chunk `ch` (rows beyond the utterance / outside the image become zeros)
-    auto fetch = [&](int ch) {
-        const int b = ch / p.chunks_per_image;
-        const int off = (ch - b * p.chunks_per_image) * WKC;
-        const int npx = min(WKC, HW - off);
-        const long long m0 = (long long)b * HW + off;
-        const int h0 = off / W, w0 = off - h0 * W;
-        w0_next = w0;
-        // padded index of (b,h,w): ((b*(H+1) + h) * (W+1)) + w; window row 0 <-> padded index P(m0) - (W+2)
-        const long long pbase = ((long long)b * (H + 1) + h0) * (W + 1) + w0 - (W + 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = srow + 16 * k;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < npx) v = *reinterpret_cast<const f32x4*>(p.g + (size_t)(m0 + row) * Cout + n0 + scc * 4);
-            gr[k] = v;
-        }
-        // decode this thread's first window row once, then step by 16 padded positions with carries
-        long long pidx = pbase + srow;
-        long long t2 = pidx >= 0 ? pidx / (W + 1) : 0;
-        int wq = pidx >= 0 ? (int)(pidx - t2 * (W + 1)) : 0;
-        int hq = pidx >= 0 ? (int)(t2 % (H + 1)) : 0;
-        long long bq = pidx >= 0 ? t2 / (H + 1) : 0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (srow + 16 * k < p.xrows && pidx >= 0 && wq < W && hq < H && bq < p.B)
-                v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(bq * H + hq) * W + wq) * Cin + c0 + scc * 4);
-            xr[k] = v;
-            if (pidx >= 0) {
-                wq += 16;
-                while (wq >= W + 1) {
-                    wq -= W + 1;
-                    if (++hq == H + 1) { hq = 0; ++bq; }
-                }
-                pidx += 16;
-            } else {
-                pidx += 16;
-                if (pidx >= 0) {
-                    t2 = pidx / (W + 1);
-                    wq = (int)(pidx - t2 * (W + 1));
-                    hq = (int)(t2 % (H + 1));
-                    bq = t2 / (H + 1);
-                }
-            }
-        }
-    };
-    // split and park the fetched chunk in LDS
-    auto park = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t h0_, l0_, h1_, l1_;
-            wsplit2(gr[k][0], gr[k][1], h0_, l0_);
-            wsplit2(gr[k][2], gr[k][3], h1_, l1_);
-            const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
-            *reinterpret_cast<uint2*>(Ghi + o) = make_uint2(h0_, h1_);
-            if (SPLIT) *reinterpret_cast<uint2*>(Glo + o) = make_uint2(l0_, l1_);
-        }
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            const int r = srow + 16 * k;
-            if (r < p.xrows) {
-                uint32_t h0_, l0_, h1_, l1_;
-                wsplit2(xr[k][0], xr[k][1], h0_, l0_);
-                wsplit2(xr[k][2], xr[k][3], h1_, l1_);
-                const int o = wg_off(r, scc >> 2) + (scc & 3) * 8;
-                *reinterpret_cast<uint2*>(Xhi + o) = make_uint2(h0_, h1_);
-                if (SPLIT) *reinterpret_cast<uint2*>(Xlo + o) = make_uint2(l0_, l1_);
-            }
-        }
-        if (tid < WKC) Ltab[tid] = tid + (w0_next + tid) / W + (W + 2);   // chunk pixel j -> window row (row ends add one)
-    };
-
-    if (chunk_lo < chunk_hi) fetch(chunk_lo);
-    for (int ch = chunk_lo; ch < chunk_hi; ++ch) {
-        park();
-        __syncthreads();
-        if (ch + 1 < chunk_hi) fetch(ch + 1);     // in flight during the MFMA section
-
+    __syncthreads();
+    for (int ci = 0; ci < nch; ++ci) {
+        const char* Ghi = smem + (ci & 1) * bufsz;
+        const char* Glo = Ghi + WKC * 128;
+        const char* Xhi = Glo + WKC * 128;
+        const int* Ltab = reinterpret_cast<const int*>(Xhi + 2 * xplane);
         // ---- MFMA: two K steps of 32 pixels; the fragments of tap t+1 are requested before tap t's MFMAs issue
 #pragma unroll
-        for (int k0 = 0; k0 < WKC; k0 += 32) {
+        for (int k0 = 0; k0 < (DASV_WGRAD_DIAG == 2 ? 0 : WKC); k0 += 32) {
             const int j0 = k0 + 8 * grp + q, j1 = j0 + 4;            // this lane's rows of the two 4-row blocks
             const int col = 4 * pp * 2;                               // byte offset of this lane's 4 columns in a 16-col block
             bf16x8 gh[4], gl[4];
@@ -194,7 +241,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(const WgradParams p)
                 const char* x0 = Xhi + wg_off(r0 + toff, wv) + col;
                 const char* x1 = Xhi + wg_off(r1 + toff, wv) + col;
                 xh = tr_frag(x0, x1);
-                if (SPLIT) xl = tr_frag(x0 + (size_t)p.xrows * 128, x1 + (size_t)p.xrows * 128);
+                if (SPLIT) xl = tr_frag(x0 + xplane, x1 + xplane);
             };
             bf16x8 xh[2], xl[2];
             xfrag(0, xh[0], xl[0]);
@@ -252,6 +299,10 @@ static void wgrad_plan(int B, int H, int W, int Cin, int Cout, WgradParams& p) {
     p.chunks_per_split = (total + S - 1) / S;
     p.S = (total + p.chunks_per_split - 1) / p.chunks_per_split;
     p.xrows = wgrad_xrows(W);
+    // the per-lane division by W (window-row table) has numerators below W + 64 and W <= 80: numerator * W < 65536, where
+    // the multiply-shift form is exact
+    p.magic_w = 65536 / W + 1;
+    p.hcarries = (16 / (W + 1) + 1 + H) / (H + 1);
 }
 
 }  // namespace dasv
@@ -270,19 +321,21 @@ int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw,
     if (x == nullptr || g == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return DASV_E_SHAPE;
     if ((long long)B * (H + 1) * (W + 1) > 0x7fffffffLL / 4) return DASV_E_SHAPE;
+    // operands are addressed through 32-bit buffer offsets
+    if ((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= 0xffffffffLL) return DASV_E_SHAPE;
     if (mode != 0 && mode != 1) return DASV_E_DTYPE;
     dasv::WgradParams p;
     dasv::wgrad_plan(B, H, W, Cin, Cout, p);
     if (workspace_bytes < (size_t)p.S * Cout * 9 * Cin * sizeof(float)) return DASV_E_WORKSPACE;
     p.x = x; p.g = g; p.part = static_cast<float*>(workspace);
-    // both planes are always carved (the bf16 mode simply leaves the lo planes unused)
-    const size_t lds = 2 * (size_t)dasv::WKC * 128 + 2 * (size_t)p.xrows * 128 + dasv::WKC * sizeof(int) + 16;
-    if (lds > 160 * 1024 || W > 80) return DASV_E_SHAPE;
+    // two buffers; both planes are always carved (the bf16 mode simply leaves the lo planes unused)
+    if (W > 80) return DASV_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)(p.ctiles * p.ntiles * p.S)), block(256);
+    const dim3 grid((unsigned)(p.ctiles * p.ntiles * p.S)), block(512);
     const int nx = (p.xrows + 15) / 16;
 #define DASV_LAUNCH_WGRAD(SP, NXV)                                                                                 \
     do {                                                                                                           \
+        const size_t lds = 2 * dasv::wgrad_buffer_bytes(NXV);                                                      \
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_wgrad_kernel<SP, NXV>),    \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
         if (e2 != hipSuccess) return (int)e2;                                                                      \
