@@ -64,18 +64,21 @@ class _VGG(nn.Module):
         self.fuse_first_block = False
         self._packed = {}
 
-    def _conv_relu(self, name, h):
+    def _use_hip_conv(self, name, h):
         conv = getattr(self, name)
-        use_hip = (self.conv_mode != "torch" and h.is_cuda and h.dtype == torch.float32
-                   and not torch.is_autocast_enabled() and conv.weight.dtype == torch.float32
-                   and _hipconv.supported(conv.in_channels, conv.out_channels))
-        if not use_hip:
+        return (self.conv_mode != "torch" and h.is_cuda and h.dtype == torch.float32
+                and not torch.is_autocast_enabled() and conv.weight.dtype == torch.float32
+                and _hipconv.supported(conv.in_channels, conv.out_channels))
+
+    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False):
+        conv = getattr(self, name)
+        if not self._use_hip_conv(name, h):
             return F.relu(conv(h))
         key = (name, h.device.index)   # nn.DataParallel replicas share this dict: one packed copy per device
         packed = self._packed.get(key)
         if packed is None:
             packed = self._packed[key] = _hipconv.PackedConvWeights()
-        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode)
+        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode, grad_premasked, mask_input_grad)
 
     def _hip_front(self, x):
         """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
@@ -110,12 +113,17 @@ class _VGG(nn.Module):
             if self.channels_last and h.is_cuda:
                 h = h.contiguous(memory_format=torch.channels_last)
         for blk in range(1, self.n_blocks + 1):
+            n1, n2 = "conv%d1" % blk, "conv%d2" % blk
+            # Backward fusion between neighbours that both run on the HIP kernels (conv.conv3x3_bias_relu docstring): the
+            # ReLU mask of convX1 is applied by convX2's data-gradient kernel, that of convX2 by the pool's backward.
+            hip2 = self._use_hip_conv(n2, h)
+            pool_hip = hip and h.dtype == torch.float32
             if not (hip and blk == 1):
-                h = self._conv_relu("conv%d1" % blk, h)
+                h = self._conv_relu(n1, h, grad_premasked=hip2)
             if not (fused_first and blk == 1):
-                h = self._conv_relu("conv%d2" % blk, h)
-            if hip and h.dtype == torch.float32:
-                h = _hipconv.maxpool2x2_ceil_autograd(h) if grad else _hipconv.maxpool2x2_ceil(h)
+                h = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True)
+            if pool_hip and h.dtype == torch.float32:
+                h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2) if grad else _hipconv.maxpool2x2_ceil(h)
             else:
                 h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f

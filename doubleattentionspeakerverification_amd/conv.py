@@ -53,14 +53,19 @@ class PackedConvWeights:
         return self.hi, self.lo
 
 
-def _launch(x, hi, lo, bias, cout, mode, relu=1):
+def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None):
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                             None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout, relu,
-                                             torch.cuda.current_stream(x.device).cuda_stream)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if mask is not None:   # y = conv(x) where mask > 0 else 0 (no bias, no ReLU): the fused data-gradient form
+            rc = lib.dasv_conv3x3_masked_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
+                                              y.data_ptr(), B, H, W, cin, cout, stream)
+        else:
+            rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                 None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout,
+                                                 relu, stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_nhwc")
     return y
 
@@ -93,19 +98,22 @@ def conv3x3_wgrad(x, g, mode="split"):
 
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mode):
+    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad):
         hi, lo = packed.get(weight, mode)
         y = _launch(x, hi, lo, bias, weight.shape[0], mode)
         ctx.save_for_backward(x, weight, y)
         ctx.has_bias = bias is not None
         ctx.mode = mode
+        ctx.grad_premasked = grad_premasked
+        ctx.mask_input_grad = mask_input_grad
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        # ReLU backward in one pass (g = gy where y > 0 else 0)
-        g = torch.ops.aten.threshold_backward(gy.contiguous(memory_format=torch.channels_last), y, 0.0)
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        # ReLU backward in one pass (g = gy where y > 0 else 0) — unless the consumer of y already applied it
+        g = gy if ctx.grad_premasked else torch.ops.aten.threshold_backward(gy, y, 0.0)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = None
         bmode = BACKWARD_MODE[ctx.mode]
@@ -117,7 +125,9 @@ class _ConvReLUFn(torch.autograd.Function):
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
             pk = PackedConvWeights()
             hi, lo = pk.get(wt, bmode)
-            gx = _launch(g, hi, lo, None, cin, bmode, relu=0)
+            # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
+            # backward is applied in this kernel's epilogue
+            gx = _launch(g, hi, lo, None, cin, bmode, relu=0, mask=x if ctx.mask_input_grad else None)
             want_x = False
         gw = gb = None
         if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
@@ -130,14 +140,22 @@ class _ConvReLUFn(torch.autograd.Function):
             gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
                 g, x, weight, [cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                 [want_x, want_w, want_b])
-            gx = gx2 if want_x else gx
+            if want_x:
+                gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
             gw = gw2 if want_w else gw
             gb = gb2 if want_b else gb
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split"):
-    """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last."""
+def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False):
+    """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
+
+    Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
+      grad_premasked   the one consumer of the returned tensor multiplies the gradient it sends back by (y > 0) itself
+                       (a following conv3x3_bias_relu(..., mask_input_grad=True) or maxpool2x2_ceil_autograd(...,
+                       relu_input=True)), so this layer skips its own ReLU-mask pass;
+      mask_input_grad  x is the ReLU output of a layer that was called with grad_premasked=True: the gradient w.r.t. x
+                       is multiplied by (x > 0) in the data-gradient kernel's epilogue."""
     if not x.is_cuda:
         raise RuntimeError("conv3x3_bias_relu runs on the GPU only (libdasv_hip.so); no CPU fallback")
     if x.dtype != torch.float32 or not supported(weight.shape[1], weight.shape[0]):
@@ -146,7 +164,7 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split"):
         x = x.contiguous(memory_format=torch.channels_last)
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
-    return _ConvReLUFn.apply(x, weight, b, packed, mode)
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias):
@@ -201,11 +219,12 @@ class _MaxPoolFn(torch.autograd.Function):
     """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward (arg-max recomputed)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, relu_input):
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         y = maxpool2x2_ceil(x)
         ctx.save_for_backward(x)
+        ctx.relu_input = relu_input
         return y
 
     @staticmethod
@@ -215,16 +234,19 @@ class _MaxPoolFn(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x, memory_format=torch.channels_last)
+        fn = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc if ctx.relu_input else lib.dasv_maxpool2x2_ceil_bwd_nhwc
         with torch.cuda.device(x.device):
-            rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C,
-                                                   torch.cuda.current_stream(x.device).cuda_stream)
+            rc = fn(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
-        return gx
+        return gx, None
 
 
-def maxpool2x2_ceil_autograd(x):
-    """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors."""
-    return _MaxPoolFn.apply(x)
+def maxpool2x2_ceil_autograd(x, relu_input=False):
+    """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors.
+
+    relu_input=True: x is the output of a conv3x3_bias_relu(..., grad_premasked=True) call and nothing else consumes it —
+    the backward then also passes the gradient through that ReLU (one fused pass instead of two)."""
+    return _MaxPoolFn.apply(x, relu_input)
 
 
 class _Conv11ReLUFn(torch.autograd.Function):

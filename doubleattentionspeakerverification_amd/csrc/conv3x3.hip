@@ -29,6 +29,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CBM = 128, CBN = 128, CBK = 64;
 
+// timing experiments only (tools/conv_diag.py builds this file with -DDASV_CONV_DIAG=n; results are wrong then):
+// 1 = the window kernel stages only the first channel slab's window, 2 = no MFMA section, 3 = weights staged once
+#ifndef DASV_CONV_DIAG
+#define DASV_CONV_DIAG 0
+#endif
+
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;   // inputs are finite activations/weights
@@ -98,6 +104,7 @@ struct ConvParams {
     const uint16_t* whi;   // [Cout][9][Cin]
     const uint16_t* wlo;
     const float* bias;     // [Cout] or null
+    const float* mask;     // [B,H,W,Cout] or null: outputs are zeroed where mask <= 0 (a ReLU's backward, fused)
     float* y;              // [B,H,W,Cout]
     int B, H, W, Cin, Cout;
     int M;                 // B*H*W
@@ -254,6 +261,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask != nullptr && !(p.mask[(size_t)m * p.Cout + n] > 0.f)) v = 0.f;
                     p.y[(size_t)m * p.Cout + n] = v;
                 }
             }
@@ -424,21 +432,22 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     int it = 0;
     for (int sl = 0; sl < nslab; ++sl) {
         const int c0 = sl * CBK;
-        if (!C1) load_window(c0);
+        if (!C1 && (DASV_CONV_DIAG != 1 || sl == 0)) load_window(c0);
         if (DBUF && sl > 0) __syncthreads();   // every wave is done reading the previous slab's window
         if (C1) stage_window_c1(c0);
-        else store_window();
+        else if (DASV_CONV_DIAG != 1 || sl == 0) store_window();
         for (int tap = 0; tap < 9; ++tap, ++it) {
             // DBUF: the buffer written now was last read two iterations ago, and every wave passed the barrier of
             // the previous iteration only after finishing that read -> ONE barrier per tap.
             char* Bhi = Bbase + ((DBUF && (it & 1)) ? 32768 : 0);
-            store_b(Bhi);
+            if (DASV_CONV_DIAG != 3 || it == 0) store_b(Bhi);
             __syncthreads();
-            if (tap < 8) load_b(tap + 1, c0);
+            if (DASV_CONV_DIAG == 3) {
+            } else if (tap < 8) load_b(tap + 1, c0);
             else if (sl + 1 < nslab) load_b(0, c0 + CBK);
             const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {
                 const int slot = kk * 4 + fq;
                 bf16x8 bh[4], bl[4];
 #pragma unroll
@@ -485,6 +494,11 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             if (m < p.M) {
                 f32x4 v = acc[i][j] + bv;
                 if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                if (p.mask != nullptr) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+                }
                 *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
             }
         }
@@ -521,8 +535,8 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 }
 
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
-                          const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu,
-                          dasv_stream_t stream) {
+                          const void* w_lo, const float* bias, const float* mask, float* y, int B, int H, int W, int Cin,
+                          int Cout, int relu, dasv_stream_t stream) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -530,7 +544,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
     if (mode < 0 || mode > 2) return DASV_E_DTYPE;
     dasv::ConvParams p;
-    p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.y = y;
+    p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.mask = mask; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
     p.mel = mel; p.w1 = w1; p.b1 = b1;
     hipStream_t s = (hipStream_t)stream;
@@ -585,13 +599,19 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
-    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, y, B, H, W, Cin, Cout, relu, stream);
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, y, B, H, W, Cin, Cout, relu, stream);
+}
+
+int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y, int B,
+                             int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask == nullptr) return DASV_E_NULL;
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, nullptr, mask, y, B, H, W, Cin, Cout, 0, stream);
 }
 
 int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,
                                            const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cmid,
                                            int Cout, dasv_stream_t stream) {
-    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, y, B, H, W, Cmid, Cout, 1, stream);
+    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, nullptr, y, B, H, W, Cmid, Cout, 1, stream);
 }
 
 }  // extern "C"

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
 // all of the window's input gradients: gy to the arg-max, zero elsewhere.  No indices tensor, no atomics, no memset.
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
-                                                                  long long nvec) {
+                                                                  long long nvec, int relu_mask) {
     const int cq = C >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         const bool hw = w0 + 1 < W, hh = h0 + 1 < H;
         const size_t o1 = base + C, o2 = base + (size_t)W * C, o3 = o2 + C;
         const f4 v0 = *reinterpret_cast<const f4*>(x + base);
-        const f4 g = *reinterpret_cast<const f4*>(gy + (size_t)op * C + q * 4);
+        f4 g = *reinterpret_cast<const f4*>(gy + (size_t)op * C + q * 4);
         f4 m = v0;
         int arg[4] = {0, 0, 0, 0};
         f4 v1, v2, v3;
@@ -98,6 +98,10 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (v3[c] > m[c] || v3[c] != v3[c]) { m[c] = v3[c]; arg[c] = 3; } }
         f4 r0, r1, r2, r3;
+        if (relu_mask) {   // x is a ReLU's output: pass the gradient through that ReLU too (zero where the maximum is not > 0)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[c] = m[c] > 0.f ? g[c] : 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             r0[c] = arg[c] == 0 ? g[c] : 0.f; r1[c] = arg[c] == 1 ? g[c] : 0.f;
@@ -200,7 +204,8 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
     return (int)hipGetLastError();
 }
 
-int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream) {
+static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
+                              dasv_stream_t stream) {
     if (x == nullptr || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -208,8 +213,17 @@ int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, in
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
-                       C, Ho, Wo, nvec);
+                       C, Ho, Wo, nvec, relu_mask);
     return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream) {
+    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 0, stream);
+}
+
+int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
+                                       dasv_stream_t stream) {
+    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 1, stream);
 }
 
 size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {

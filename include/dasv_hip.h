@@ -146,6 +146,11 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+/* y = conv3x3(x) where mask > 0, else 0 (mask [B,H,W,Cout]).  The data gradient of `F.relu(convX2(F.relu(convX1(h))))`
+ * w.r.t. convX1's pre-activation in one launch: x = gradient at convX2's output (already masked), weights = convX2's
+ * transposed and flipped, mask = convX2's input (= convX1's ReLU output).  Saves autograd's threshold_backward pass. */
+int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y, int B,
+                             int H, int W, int Cin, int Cout, dasv_stream_t stream);
 
 /* Two layers in one launch: y = relu(conv3x3(relu(conv3x3_1ch(mel) + b1)) + bias) — the first block of the VGG front-end
  * (`F.relu(self.conv12(F.relu(self.conv11(x))))`, CNNs.py:38-39 / 72-73).  The one-channel layer's activations are
@@ -177,6 +182,10 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
  * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d
  * backward for CNNs.py:40,44,48 / 74,78,82,86. */
 int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream);
+/* Same, for x = a ReLU's output (`F.relu(self.convX2(..))` feeding the pool): the gradient is also passed through that
+ * ReLU (zero where the window maximum is not > 0), which saves the separate mask pass over [B,H,W,C]. */
+int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
+                                       dasv_stream_t stream);
 /* Backward of the one-input-channel layer: from x [B,H,W], its output y [B,H,W,Cout] and gy (gradient w.r.t. y, before
  * the ReLU mask): gw [Cout,1,3,3] and gb [Cout] (or NULL), both OVERWRITTEN; fixed-order reduction.  Replaces autograd's
  * backward of `F.relu(self.conv11(x))` (CNNs.py:38 / 72).  workspace: dasv_conv3x3_c1_bwd_workspace_bytes(). */

@@ -426,3 +426,90 @@ def test_hip_maxpool_and_conv11_backward_match_torch():
     (yr * gy).sum().backward()
     np.testing.assert_allclose(g1[0].cpu().numpy(), w.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()))
     np.testing.assert_allclose(g1[1].cpu().numpy(), b.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("ks", [1024, 512])
+def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
+    """All gradients of the VGG4L front-end through the HIP path — convs, pools, conv11, with the ReLU masks fused into
+    the neighbouring backward kernels.  kernel_size 512 mixes HIP and MIOpen layers (conv12 has 64 output channels),
+    which exercises the fusion protocol's fallbacks.  Three checks:
+      (a) fused and unfused HIP backward are bit-identical (same forward, so no arg-max / ReLU-sign flips);
+      (b) every HIP conv layer's weight/bias gradient equals ATen's convolution_backward on the SAME saved tensors;
+      (c) against PyTorch-ROCm's own path the gradient vectors agree in direction (a single arg-max flip caused by the
+          5e-6 forward difference moves one pixel's gradient — percent-level for one channel in a 2-utterance batch —
+          so an element-wise bound against a different forward is not meaningful here)."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    from doubleattentionspeakerverification_amd import conv as C
+    torch.manual_seed(5)
+    net = VGG4L(ks).to(DEV).train()
+    x = torch.from_numpy(rnd(61, 2, 45, 80)).to(DEV)
+    orig_conv, orig_pool = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd
+    cap = {}
+
+    def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, fuse=True):
+        y = orig_conv(xx, w, b, packed, mode, premasked and fuse, mask_in and fuse)
+        name = [k for k, v in net.named_parameters() if v is w][0].split(".")[0]
+        cap[name] = dict(x=xx.detach(), y=y.detach(), premasked=premasked and fuse)
+        y.register_hook(lambda g, name=name: cap[name].__setitem__("gy", g.detach().clone()))
+        return y
+
+    gout, grads = None, {}
+    for mode in ("torch", "fused", "unfused"):
+        fuse = mode == "fused"
+        monkeypatch.setattr(C, "conv3x3_bias_relu", lambda *a, fuse=fuse, **k: capturing(*a, fuse=fuse, **k))
+        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, fuse=fuse: orig_pool(t, relu_input and fuse))
+        net.conv_mode = "torch" if mode == "torch" else "split"
+        net.zero_grad()
+        cap.clear()
+        y = net(x)
+        if gout is None:
+            gout = torch.from_numpy(rnd(62, *y.shape)).to(DEV)
+        (y * gout).sum().backward()
+        grads[mode] = {k: v.grad.clone() for k, v in net.named_parameters()}
+        if mode == "torch":
+            continue
+        assert len(cap) == (7 if ks == 1024 else 6)
+        for name, d in cap.items():                                   # (b)
+            conv_ = getattr(net, name)
+            if d["premasked"]:
+                assert torch.equal(d["gy"], d["gy"] * (d["y"] > 0)), name      # the consumer really applied the mask
+            g = d["gy"] * (d["y"] > 0)
+            _, gw, gb = torch.ops.aten.convolution_backward(g, d["x"], conv_.weight.detach(), [conv_.out_channels], [1, 1], [1, 1],
+                                                            [1, 1], False, [0, 0], 1, [False, True, True])
+            assert float((conv_.weight.grad - gw).abs().max()) <= 2e-5 * float(gw.abs().max()), name
+            assert float((conv_.bias.grad - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), name
+    for k in grads["torch"]:
+        if ks == 1024:                                                                                         # (a)
+            assert torch.equal(grads["fused"][k], grads["unfused"][k]), k
+        else:   # below a MIOpen layer (conv12 at this width) the backward is not run-to-run deterministic
+            assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 1e-5 * float(grads["unfused"][k].abs().max()), k
+        cosv = float(torch.nn.functional.cosine_similarity(grads["fused"][k].flatten().double(),
+                                                           grads["torch"][k].flatten().double(), dim=0))
+        assert cosv > 0.9995, (k, cosv)                                                                       # (c)
+
+
+def test_masked_conv_and_relu_pool_backward_entry_points():
+    """dasv_conv3x3_masked_nhwc (data gradient with the lower layer's ReLU mask in the epilogue) and
+    dasv_maxpool2x2_ceil_relu_bwd_nhwc (pool backward composed with the ReLU below it) against the two-pass torch forms."""
+    from doubleattentionspeakerverification_amd import conv, _lib
+    lib = _lib.load()
+    g = torch.from_numpy(rnd(71, 2, 128, 11, 9)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.from_numpy(rnd(72, 128, 128, 3, 3, scale=0.05)).to(DEV)
+    xin = torch.relu(torch.from_numpy(rnd(73, 2, 128, 11, 9))).to(DEV).contiguous(memory_format=torch.channels_last)
+    wt = w.transpose(0, 1).flip(2, 3).contiguous()
+    hi, lo = conv.PackedConvWeights().get(wt, "split")
+    got = conv._launch(g, hi, lo, None, 128, "split", relu=0, mask=xin)
+    ref = torch.nn.functional.conv2d(g.double().cpu(), wt.double().cpu(), None, padding=1) * (xin.cpu() > 0)
+    assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got == 0, (got == 0) | (xin <= 0)) and bool(((got != 0) <= (xin > 0)).all())
+    # pool backward through a ReLU output full of zeros
+    y = torch.relu(torch.from_numpy(rnd(74, 2, 64, 9, 7))).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pre = y.detach().clone().requires_grad_(True)
+    gy = torch.from_numpy(rnd(75, 2, 64, 5, 4)).to(DEV)
+    torch.nn.functional.max_pool2d(torch.relu(pre), 2, stride=2, ceil_mode=True).backward(gy)
+    gx = torch.empty_like(y, memory_format=torch.channels_last)
+    gyc = gy.contiguous(memory_format=torch.channels_last)
+    rc = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc(y.data_ptr(), gyc.data_ptr(), gx.data_ptr(), 2, 9, 7, 64,
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(gx, pre.grad)
