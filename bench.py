@@ -331,6 +331,26 @@ def main():
                         "launches_per_step": len(ctimer.rec) // max(1, args.steps),
                         "mfma_flops_executed_per_algorithmic_flop": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4)}
+        # reduced-precision companion (never the headline `value`): same step with fp16 conv operands (fp32 accumulate,
+        # fp32 activations), with its measured embedding error against the fp32-grade path on the same batch
+        reduced = None
+        if world == 1 and args.workload == "embed" and args.conv == "split" and compute_dtype == torch.float32:
+            ref_emb = step(0).float()
+            net.front_end.conv_mode = "fp16"
+            run_steps(0, 2)
+            torch.cuda.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
+            run_steps(0, args.steps)
+            r1.record()
+            torch.cuda.synchronize()
+            emb16 = step(0).float()
+            net.front_end.conv_mode = args.conv
+            ms16 = r0.elapsed_time(r1) / args.steps
+            reduced = {"conv_operands": "fp16 (v_mfma_f32_16x16x32_f16, fp32 accumulate)", "ms_per_step": round(ms16, 4),
+                       "value": round(B / ms16 * 1e3, 2), "unit": "utterance-embeddings/s",
+                       "embedding_max_rel_err_vs_fp32_grade_path": float((emb16 - ref_emb).abs().max() / ref_emb.abs().max()),
+                       "min_cosine_vs_fp32_grade_path": float(torch.nn.functional.cosine_similarity(emb16, ref_emb, dim=-1).min())}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
@@ -347,6 +367,8 @@ def main():
             "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
             "config": config, "roofline": roofline, "roofline_pooling": pool_roof, "cpu_baseline": cpu,
         }
+        if reduced is not None:
+            out["reduced_precision_fp16_operands"] = reduced
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
