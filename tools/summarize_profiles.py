@@ -72,18 +72,28 @@ for run in ("pool", "embed"):
     if run == "embed":
         rows = list(csv.DictReader(open(one("embed_trace/*/*kernel_stats.csv"))))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        steps = 8.0  # warmup 2 + steps 6 in tools/collect_profiles.sh
-        md.append("* kernel mix of the step (all GPU kernels, %.2f ms of kernel time per step):\n" % (tot / steps / 1e6))
-        for r in rows[:8]:
+        # passes in the run: warm-up 2 + timed 6 + 1 reference pass in fp32-grade (split) mode, then the same 9 in the
+        # fp16-operand companion mode (bench.py's `reduced_precision_fp16_operands`); conv kernels carry the mode in their
+        # first template argument (0 = split, 2 = fp16), the other kernels are shared by both.
+        split = [r for r in rows if "conv3x3_window_kernel<0" in r["Name"]]
+        half = [r for r in rows if "conv3x3_window_kernel<2" in r["Name"]]
+        passes = sum(int(r["Calls"]) for r in split) / 7.0
+        passes16 = sum(int(r["Calls"]) for r in half) / 7.0
+        md.append("* passes in this run: %d fp32-grade (split-bf16 conv operands) + %d fp16-operand companion passes\n" % (passes, passes16))
+        md.append("* kernel mix of the whole run (all GPU kernels, %.2f ms of kernel time):\n" % (tot / 1e6))
+        for r in rows[:9]:
             md.append("  * `%s` — %s calls, avg %.1f us, %.1f %% of kernel time\n"
                       % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
-        conv = [r for r in rows if "conv3x3_window_kernel" in r["Name"]]
-        if conv:
-            per_step = sum(float(c["TotalDurationNs"]) for c in conv) / steps / 1e3
-            flops = 64 * (39.13e9 - 0.055e9)   # seven wide layers of VGG4L/1024 at T=300 (SURVEY appendix D.1 minus conv11)
-            md.append("* `conv3x3_window_kernel`: %.0f us per step over 7 launches -> %.0f TFLOP/s algorithmic (x3 executed on the "
-                      "MFMA pipe in split mode = %.0f TFLOP/s, %.0f %% of the 2.5 PFLOP/s dense bf16 peak)\n"
+        flops = 64 * (39.13e9 - 0.055e9)   # seven wide layers of VGG4L/1024 at T=300 (SURVEY appendix D.1 minus conv11)
+        if split:
+            per_step = sum(float(c["TotalDurationNs"]) for c in split) / passes / 1e3
+            md.append("* `conv3x3_window_kernel<0,..>` (split mode, the headline): %.0f us per step over 7 launches -> %.0f TFLOP/s "
+                      "algorithmic (x3 executed on the MFMA pipe = %.0f TFLOP/s, %.0f %% of the 2.5 PFLOP/s dense bf16 peak)\n"
                       % (per_step, flops / per_step / 1e6, 3 * flops / per_step / 1e6, 100 * 3 * flops / per_step / 1e6 / 2500))
+        if half:
+            per_step = sum(float(c["TotalDurationNs"]) for c in half) / passes16 / 1e3
+            md.append("* `conv3x3_window_kernel<2,..>` (fp16 operands, companion): %.0f us per step -> %.0f TFLOP/s (%.0f %% of peak)\n"
+                      % (per_step, flops / per_step / 1e6, 100 * flops / per_step / 1e6 / 2500))
     if bl:
         pr = bl.get("roofline_pooling") or bl["roofline"]
         md.append("* bench.py under the profiler: value %.1f %s; pooling-kernel avg_launch_us %.2f by events (includes the event/launch gap)\n"
