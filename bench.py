@@ -83,12 +83,12 @@ class ConvTimer:
         self.active = False
         inner = convmod._launch
 
-        def timed(x, hi, lo, bias, cout, mode, relu=1, mask=None):
+        def timed(x, hi, lo, bias, cout, mode, *a, **k):
             if not self.active:
-                return inner(x, hi, lo, bias, cout, mode, relu, mask)
+                return inner(x, hi, lo, bias, cout, mode, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(torch.cuda.current_stream(x.device))
-            y = inner(x, hi, lo, bias, cout, mode, relu, mask)
+            y = inner(x, hi, lo, bias, cout, mode, *a, **k)
             e.record(torch.cuda.current_stream(x.device))
             B, cin, H, W = x.shape
             self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))

@@ -70,7 +70,7 @@ class _VGG(nn.Module):
                 and not torch.is_autocast_enabled() and conv.weight.dtype == torch.float32
                 and _hipconv.supported(conv.in_channels, conv.out_channels))
 
-    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False):
+    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None):
         conv = getattr(self, name)
         if not self._use_hip_conv(name, h):
             return F.relu(conv(h))
@@ -78,7 +78,8 @@ class _VGG(nn.Module):
         packed = self._packed.get(key)
         if packed is None:
             packed = self._packed[key] = _hipconv.PackedConvWeights()
-        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode, grad_premasked, mask_input_grad)
+        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode, grad_premasked, mask_input_grad,
+                                          link_in, link_out)
 
     def _hip_front(self, x):
         """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
@@ -116,14 +117,18 @@ class _VGG(nn.Module):
             n1, n2 = "conv%d1" % blk, "conv%d2" % blk
             # Backward fusion between neighbours that both run on the HIP kernels (conv.conv3x3_bias_relu docstring): the
             # ReLU mask of convX1 is applied by convX2's data-gradient kernel, that of convX2 by the pool's backward.
+            # The kernel that applies a mask also leaves the masked gradient's per-channel sums (the bias gradient of the
+            # layer it masks for) in a dict both calls share.
             hip2 = self._use_hip_conv(n2, h)
             pool_hip = hip and h.dtype == torch.float32
+            l1, l2 = ({}, {}) if grad else (None, None)
             if not (hip and blk == 1):
-                h = self._conv_relu(n1, h, grad_premasked=hip2)
+                h = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1)
             if not (fused_first and blk == 1):
-                h = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True)
+                h = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True, link_in=l2,
+                                    link_out=None if (hip and blk == 1) else l1)   # conv11's kernel sums its own bias gradient
             if pool_hip and h.dtype == torch.float32:
-                h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2) if grad else _hipconv.maxpool2x2_ceil(h)
+                h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2) if grad else _hipconv.maxpool2x2_ceil(h)
             else:
                 h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f

@@ -34,14 +34,16 @@ SIGNATURES = {
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_maxpool2x2_ceil_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_bwd_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),

@@ -53,15 +53,21 @@ class PackedConvWeights:
         return self.hi, self.lo
 
 
-def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None):
+def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None):
+    """colsum (with mask): a dict that receives 'gb' = per-channel sums of the masked output (fixed-order partial sums
+    from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if mask is not None:   # y = conv(x) where mask > 0 else 0 (no bias, no ReLU): the fused data-gradient form
+            rows = lib.dasv_conv3x3_colsum_rows(B, H, W) if colsum is not None else 0
+            part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             rc = lib.dasv_conv3x3_masked_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
-                                              y.data_ptr(), B, H, W, cin, cout, stream)
+                                              y.data_ptr(), None if part is None else part.data_ptr(), B, H, W, cin, cout, stream)
+            if part is not None and rc == 0:
+                colsum["gb"] = part.sum(dim=0)
         else:
             rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
                                                  None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout,
@@ -98,7 +104,7 @@ def conv3x3_wgrad(x, g, mode="split"):
 
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad):
+    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out):
         hi, lo = packed.get(weight, mode)
         y = _launch(x, hi, lo, bias, weight.shape[0], mode)
         ctx.save_for_backward(x, weight, y)
@@ -106,6 +112,7 @@ class _ConvReLUFn(torch.autograd.Function):
         ctx.mode = mode
         ctx.grad_premasked = grad_premasked
         ctx.mask_input_grad = mask_input_grad
+        ctx.link_in, ctx.link_out = link_in, link_out
         return y
 
     @staticmethod
@@ -127,14 +134,18 @@ class _ConvReLUFn(torch.autograd.Function):
             hi, lo = pk.get(wt, bmode)
             # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
             # backward is applied in this kernel's epilogue
-            gx = _launch(g, hi, lo, None, cin, bmode, relu=0, mask=x if ctx.mask_input_grad else None)
+            gx = _launch(g, hi, lo, None, cin, bmode, relu=0, mask=x if ctx.mask_input_grad else None,
+                         colsum=ctx.link_out if ctx.mask_input_grad else None)
             want_x = False
         gw = gb = None
         if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
             gw = conv3x3_wgrad(x, g, bmode)
             want_w = False
             if want_b:
-                gb = g.sum(dim=(0, 2, 3))
+                # the kernel that produced this (pre-masked) gradient may have left its per-channel sums behind
+                gb = ctx.link_in.pop("gb", None) if (ctx.grad_premasked and ctx.link_in is not None) else None
+                if gb is None:
+                    gb = g.sum(dim=(0, 2, 3))
                 want_b = False
         if want_x or want_w or want_b:
             gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
@@ -144,10 +155,11 @@ class _ConvReLUFn(torch.autograd.Function):
                 gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
             gw = gw2 if want_w else gw
             gb = gb2 if want_b else gb
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False):
+def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
+                      link_in=None, link_out=None):
     """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
 
     Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
@@ -155,7 +167,10 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
                        (a following conv3x3_bias_relu(..., mask_input_grad=True) or maxpool2x2_ceil_autograd(...,
                        relu_input=True)), so this layer skips its own ReLU-mask pass;
       mask_input_grad  x is the ReLU output of a layer that was called with grad_premasked=True: the gradient w.r.t. x
-                       is multiplied by (x > 0) in the data-gradient kernel's epilogue."""
+                       is multiplied by (x > 0) in the data-gradient kernel's epilogue.
+    link_in / link_out are plain dicts shared between neighbouring calls: the kernel that produces a pre-masked gradient
+    also leaves its per-channel sums (= the producer layer's bias gradient) in `link_out["gb"]`; the layer that receives
+    that gradient passes the same dict as `link_in` and skips its own reduction pass."""
     if not x.is_cuda:
         raise RuntimeError("conv3x3_bias_relu runs on the GPU only (libdasv_hip.so); no CPU fallback")
     if x.dtype != torch.float32 or not supported(weight.shape[1], weight.shape[0]):
@@ -164,7 +179,7 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         x = x.contiguous(memory_format=torch.channels_last)
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
-    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad)
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias):
@@ -219,12 +234,13 @@ class _MaxPoolFn(torch.autograd.Function):
     """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward (arg-max recomputed)."""
 
     @staticmethod
-    def forward(ctx, x, relu_input):
+    def forward(ctx, x, relu_input, link_out):
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         y = maxpool2x2_ceil(x)
         ctx.save_for_backward(x)
         ctx.relu_input = relu_input
+        ctx.link_out = link_out
         return y
 
     @staticmethod
@@ -234,19 +250,28 @@ class _MaxPoolFn(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x, memory_format=torch.channels_last)
-        fn = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc if ctx.relu_input else lib.dasv_maxpool2x2_ceil_bwd_nhwc
         with torch.cuda.device(x.device):
-            rc = fn(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if ctx.relu_input:
+                rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if ctx.link_out is not None else 0
+                part = torch.empty((rows, C), dtype=torch.float32, device=x.device) if rows > 0 else None
+                rc = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(),
+                                                            None if part is None else part.data_ptr(), B, H, W, C, stream)
+                if part is not None and rc == 0:
+                    ctx.link_out["gb"] = part.sum(dim=0)
+            else:
+                rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
-        return gx, None
+        return gx, None, None
 
 
-def maxpool2x2_ceil_autograd(x, relu_input=False):
+def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None):
     """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors.
 
     relu_input=True: x is the output of a conv3x3_bias_relu(..., grad_premasked=True) call and nothing else consumes it —
-    the backward then also passes the gradient through that ReLU (one fused pass instead of two)."""
-    return _MaxPoolFn.apply(x, relu_input)
+    the backward then also passes the gradient through that ReLU (one fused pass instead of two), and leaves that conv's
+    bias gradient in `link_out["gb"]` (see conv3x3_bias_relu)."""
+    return _MaxPoolFn.apply(x, relu_input, link_out)
 
 
 class _Conv11ReLUFn(torch.autograd.Function):

@@ -105,6 +105,7 @@ struct ConvParams {
     const uint16_t* wlo;
     const float* bias;     // [Cout] or null
     const float* mask;     // [B,H,W,Cout] or null: outputs are zeroed where mask <= 0 (a ReLU's backward, fused)
+    float* colsum;         // [mtiles][Cout] or null (window kernel): per-channel sums of the stored tile (bias gradients)
     float* y;              // [B,H,W,Cout]
     int B, H, W, Cin, Cout;
     int M;                 // B*H*W
@@ -485,11 +486,14 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     }
 
     // epilogue: D[row = channel][col = pixel]: lane holds channels n .. n+3 of pixel m
+    float* red = reinterpret_cast<float*>(smem);   // [4 wm][128 channels] partial column sums (colsum only)
+    if (p.colsum != nullptr) __syncthreads();      // every wave is done with the LDS tiles
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -502,8 +506,18 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                     for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
                 }
                 *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
+                csum += v;
             }
         }
+        if (p.colsum != nullptr) {   // fixed-order reduction: 4 pixel blocks (above), 16 lanes (DPP), then the 4 pixel waves
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csum[r] = group_sum<16>(csum[r]);
+            if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(red + wm * 128 + wn * 64 + j * 16 + (lane >> 4) * 4) = csum;
+        }
+    }
+    if (p.colsum != nullptr) {
+        __syncthreads();
+        if (tid < 128) p.colsum[(size_t)mt * p.Cout + n0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     }
 }
 
@@ -537,8 +551,8 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 }
 
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
-                          const void* w_lo, const float* bias, const float* mask, float* y, int B, int H, int W, int Cin,
-                          int Cout, int relu, dasv_stream_t stream) {
+                          const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, int B, int H, int W,
+                          int Cin, int Cout, int relu, dasv_stream_t stream) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -546,14 +560,15 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
     if (mode < 0 || mode > 2) return DASV_E_DTYPE;
     dasv::ConvParams p;
-    p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.mask = mask; p.y = y;
+    p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.mask = mask; p.colsum = colsum; p.y = y;
+    if (colsum != nullptr && W > 80) return DASV_E_SHAPE;   // only the window kernel carries the column sums
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
     p.mel = mel; p.w1 = w1; p.b1 = b1;
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
     static int force_tile_kernel = -1;
     if (force_tile_kernel < 0) force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;
-    if (W <= 80 && (!force_tile_kernel || mel != nullptr)) {
+    if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr)) {
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
@@ -601,19 +616,25 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
-    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, y, B, H, W, Cin, Cout, relu, stream);
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, B, H, W, Cin, Cout, relu, stream);
 }
 
-int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y, int B,
-                             int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
+                             float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (mask == nullptr) return DASV_E_NULL;
-    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, nullptr, mask, y, B, H, W, Cin, Cout, 0, stream);
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, nullptr, mask, colsum_partial, y, B, H, W, Cin, Cout,
+                          0, stream);
+}
+
+int dasv_conv3x3_colsum_rows(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || W > 80) return 0;
+    return (int)(((long long)B * H * W + dasv::WBM - 1) / dasv::WBM);
 }
 
 int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,
                                            const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cmid,
                                            int Cout, dasv_stream_t stream) {
-    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, nullptr, y, B, H, W, Cmid, Cout, 1, stream);
+    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, nullptr, nullptr, y, B, H, W, Cmid, Cout, 1, stream);
 }
 
 }  // extern "C"

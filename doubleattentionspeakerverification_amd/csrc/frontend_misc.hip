@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
 // all of the window's input gradients: gy to the arg-max, zero elsewhere.  No indices tensor, no atomics, no memset.
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
-                                                                  long long nvec, int relu_mask) {
+                                                                  long long nvec, int relu_mask, float* __restrict__ colsum) {
+    // colsum (optional): [gridDim.x][C] per-channel sums of the gradient this workgroup scattered (= the bias gradient of
+    // the conv whose ReLU output was pooled).  Needs (C/4) | 256 so that a thread keeps the same four channels throughout.
+    __shared__ f4 red[256];
+    f4 csum = {0.f, 0.f, 0.f, 0.f};
     const int cq = C >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
@@ -111,6 +115,16 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         if (hw) *reinterpret_cast<f4*>(gx + o1) = r1;
         if (hh) *reinterpret_cast<f4*>(gx + o2) = r2;
         if (hw && hh) *reinterpret_cast<f4*>(gx + o3) = r3;
+        csum += g;   // exactly one of the window's inputs received g
+    }
+    if (colsum != nullptr) {
+        red[threadIdx.x] = csum;
+        __syncthreads();
+        if ((int)threadIdx.x < cq) {     // threads t, t + cq, t + 2 cq, ... hold the same channels: fixed-order sum
+            f4 t = red[threadIdx.x];
+            for (int k = threadIdx.x + cq; k < 256; k += cq) t += red[k];
+            *reinterpret_cast<f4*>(colsum + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
+        }
     }
 }
 
@@ -204,26 +218,37 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
     return (int)hipGetLastError();
 }
 
+static long long maxpool_bwd_blocks(int B, int H, int W, int C) {
+    const long long nvec = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    const long long blocks = (nvec + 255) / 256;
+    return blocks > 256 * 32 ? 256 * 32 : blocks;
+}
+
 static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
-                              dasv_stream_t stream) {
+                              float* colsum, dasv_stream_t stream) {
+    if (colsum != nullptr && (C / 4 > 256 || 256 % (C / 4) != 0)) return DASV_E_SHAPE;
     if (x == nullptr || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
-    long long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    const long long blocks = maxpool_bwd_blocks(B, H, W, C);
     hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
-                       C, Ho, Wo, nvec, relu_mask);
+                       C, Ho, Wo, nvec, relu_mask, colsum);
     return (int)hipGetLastError();
 }
 
 int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream) {
-    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 0, stream);
+    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 0, nullptr, stream);
 }
 
-int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
-                                       dasv_stream_t stream) {
-    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 1, stream);
+int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, float* colsum_partial, int B, int H, int W,
+                                       int C, dasv_stream_t stream) {
+    return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 1, colsum_partial, stream);
+}
+
+int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || C / 4 > 256 || 256 % (C / 4) != 0) return 0;
+    return (int)maxpool_bwd_blocks(B, H, W, C);
 }
 
 size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {

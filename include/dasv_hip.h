@@ -148,9 +148,12 @@ int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, cons
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 /* y = conv3x3(x) where mask > 0, else 0 (mask [B,H,W,Cout]).  The data gradient of `F.relu(convX2(F.relu(convX1(h))))`
  * w.r.t. convX1's pre-activation in one launch: x = gradient at convX2's output (already masked), weights = convX2's
- * transposed and flipped, mask = convX2's input (= convX1's ReLU output).  Saves autograd's threshold_backward pass. */
-int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y, int B,
-                             int H, int W, int Cin, int Cout, dasv_stream_t stream);
+ * transposed and flipped, mask = convX2's input (= convX1's ReLU output).  Saves autograd's threshold_backward pass.
+ * colsum_partial (optional, maps up to 80 columns): [dasv_conv3x3_colsum_rows(B,H,W)][Cout] per-channel sums of the rows of y
+ * each workgroup wrote; their sum over the first axis is convX1's bias gradient (autograd's separate `sum` pass). */
+int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
+                             float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_colsum_rows(int B, int H, int W);
 
 /* Two layers in one launch: y = relu(conv3x3(relu(conv3x3_1ch(mel) + b1)) + bias) — the first block of the VGG front-end
  * (`F.relu(self.conv12(F.relu(self.conv11(x))))`, CNNs.py:38-39 / 72-73).  The one-channel layer's activations are
@@ -184,8 +187,11 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
 int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream);
 /* Same, for x = a ReLU's output (`F.relu(self.convX2(..))` feeding the pool): the gradient is also passed through that
  * ReLU (zero where the window maximum is not > 0), which saves the separate mask pass over [B,H,W,C]. */
-int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
-                                       dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, float* colsum_partial, int B, int H, int W,
+                                       int C, dasv_stream_t stream);
+/* rows of the optional colsum_partial [rows][C] above (per-workgroup channel sums of gx = that conv's bias gradient after a
+ * sum over the first axis); 0 when C does not allow it ((C/4) must divide 256). */
+int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C);
 /* Backward of the one-input-channel layer: from x [B,H,W], its output y [B,H,W,Cout] and gy (gradient w.r.t. y, before
  * the ReLU mask): gw [Cout,1,3,3] and gb [Cout] (or NULL), both OVERWRITTEN; fixed-order reduction.  Replaces autograd's
  * backward of `F.relu(self.conv11(x))` (CNNs.py:38 / 72).  workspace: dasv_conv3x3_c1_bwd_workspace_bytes(). */

@@ -433,7 +433,8 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     """All gradients of the VGG4L front-end through the HIP path — convs, pools, conv11, with the ReLU masks fused into
     the neighbouring backward kernels.  kernel_size 512 mixes HIP and MIOpen layers (conv12 has 64 output channels),
     which exercises the fusion protocol's fallbacks.  Three checks:
-      (a) fused and unfused HIP backward are bit-identical (same forward, so no arg-max / ReLU-sign flips);
+      (a) fused and unfused HIP backward are bit-identical (same forward, so no arg-max / ReLU-sign flips) — bias gradients
+          to 2e-6, since the fused path takes them from the epilogues' per-workgroup column sums;
       (b) every HIP conv layer's weight/bias gradient equals ATen's convolution_backward on the SAME saved tensors;
       (c) against PyTorch-ROCm's own path the gradient vectors agree in direction (a single arg-max flip caused by the
           5e-6 forward difference moves one pixel's gradient — percent-level for one channel in a 2-utterance batch —
@@ -446,8 +447,9 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     orig_conv, orig_pool = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd
     cap = {}
 
-    def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, fuse=True):
-        y = orig_conv(xx, w, b, packed, mode, premasked and fuse, mask_in and fuse)
+    def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, link_in=None, link_out=None, fuse=True):
+        y = orig_conv(xx, w, b, packed, mode, premasked and fuse, mask_in and fuse, link_in if fuse else None,
+                      link_out if fuse else None)
         name = [k for k, v in net.named_parameters() if v is w][0].split(".")[0]
         cap[name] = dict(x=xx.detach(), y=y.detach(), premasked=premasked and fuse)
         y.register_hook(lambda g, name=name: cap[name].__setitem__("gy", g.detach().clone()))
@@ -457,7 +459,8 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     for mode in ("torch", "fused", "unfused"):
         fuse = mode == "fused"
         monkeypatch.setattr(C, "conv3x3_bias_relu", lambda *a, fuse=fuse, **k: capturing(*a, fuse=fuse, **k))
-        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, fuse=fuse: orig_pool(t, relu_input and fuse))
+        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, fuse=fuse:
+                            orig_pool(t, relu_input and fuse, link_out if fuse else None))
         net.conv_mode = "torch" if mode == "torch" else "split"
         net.zero_grad()
         cap.clear()
@@ -479,8 +482,10 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
             assert float((conv_.weight.grad - gw).abs().max()) <= 2e-5 * float(gw.abs().max()), name
             assert float((conv_.bias.grad - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), name
     for k in grads["torch"]:
-        if ks == 1024:                                                                                         # (a)
+        if ks == 1024 and not k.endswith(".bias"):                                                             # (a)
             assert torch.equal(grads["fused"][k], grads["unfused"][k]), k
+        elif ks == 1024:   # bias gradients: fused path sums per-workgroup partials from the kernel epilogues (other order)
+            assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 2e-6 * float(grads["unfused"][k].abs().max()), k
         else:   # below a MIOpen layer (conv12 at this width) the backward is not run-to-run deterministic
             assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 1e-5 * float(grads["unfused"][k].abs().max()), k
         cosv = float(torch.nn.functional.cosine_similarity(grads["fused"][k].flatten().double(),
@@ -509,7 +514,16 @@ def test_masked_conv_and_relu_pool_backward_entry_points():
     torch.nn.functional.max_pool2d(torch.relu(pre), 2, stride=2, ceil_mode=True).backward(gy)
     gx = torch.empty_like(y, memory_format=torch.channels_last)
     gyc = gy.contiguous(memory_format=torch.channels_last)
-    rc = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc(y.data_ptr(), gyc.data_ptr(), gx.data_ptr(), 2, 9, 7, 64,
+    rows = lib.dasv_maxpool2x2_bwd_colsum_rows(2, 9, 7, 64)
+    part = torch.empty(rows, 64, device=DEV)
+    rc = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc(y.data_ptr(), gyc.data_ptr(), gx.data_ptr(), part.data_ptr(), 2, 9, 7, 64,
                                                 torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
+    assert rc == 0 and rows > 0
     assert torch.equal(gx, pre.grad)
+    np.testing.assert_allclose(part.sum(0).cpu().numpy(), pre.grad.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # column sums of the masked data gradient (the bias gradient of the layer below)
+    link = {}
+    got2 = conv._launch(g, hi, lo, None, 128, "split", relu=0, mask=xin, colsum=link)
+    assert torch.equal(got2, got)
+    np.testing.assert_allclose(link["gb"].cpu().numpy(), got.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5,
+                               atol=1e-5 * float(got.sum(dim=(0, 2, 3)).abs().max()))
