@@ -13,7 +13,8 @@
 //     at a third of the bf16 MFMA rate — which is still ~5x the fp32 MFMA rate.
 //   BF16: hi only (one MFMA per product), 8 mantissa bits.
 //   F16:  operands rounded to fp16 (11 mantissa bits, v_mfma_f32_16x16x32_f16), one MFMA per product; activations
-//     beyond +-65504 overflow, so this is a forward/inference mode (weights come from dasv_conv3x3_pack_weights_f16).
+//     saturate at +-65504 and values below 6e-8 flush, so this is a forward/inference mode (weights come from
+//     dasv_conv3x3_pack_weights_f16).
 // Tile: 128 pixels x 128 channels x 64 (one tap's channel slab) per 256-thread workgroup; 2x2 waves, each
 // 64x64 = 4x4 MFMA tiles.  Global -> registers (next K-step, issued before the MFMAs of the current one) ->
 // LDS (XOR-swizzled 16-byte slots so ds_read_b128 fragment reads spread over the banks) -> MFMA.
@@ -59,8 +60,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int PREC>
 __device__ __forceinline__ void cvt2(float a, float b, uint32_t& hi, uint32_t& lo) {
     if (PREC == PREC_F16) {
-        const f32x2_t v = {a, b};
-        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));   // RNE; |v| > 65504 becomes inf
+        // RNE, saturating at the largest finite half (an activation beyond +-65504 must not turn the map into inf/NaN)
+        const f32x2_t v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+        hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
         lo = 0;
     } else {
         split2(a, b, hi, lo);

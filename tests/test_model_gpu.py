@@ -220,6 +220,11 @@ def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
     assert float((ys - ref).abs().max()) / scale < 2e-5
     assert float((yb - ref).abs().max()) / scale < 1e-2
     assert float((yh - ref).abs().max()) / scale < 1.25e-3   # fp16 operands: 8x tighter than bf16
+    if cin == 64:   # fp16 mode saturates instead of overflowing: a 1e6 activation gives a finite map
+        xb = x.clone()
+        xb[0, 0, 0, 0] = 1e6
+        with torch.no_grad():
+            assert torch.isfinite(conv.conv3x3_bias_relu(xb, w, b, None, "fp16")).all()
 
 
 def test_hip_conv_backward_matches_torch_autograd():
