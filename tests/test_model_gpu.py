@@ -368,10 +368,11 @@ def test_data_parallel_trainer_single_rank_matches_plain_optimizer_step():
 
 
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 9, 7, 3), (128, 64, 38, 10, 5), (64, 128, 33, 80, 2), (64, 64, 1, 1, 2),
-                                           (128, 128, 19, 5, 7)])
+                                           (128, 128, 19, 5, 7), (64, 64, 13, 8, 3), (128, 64, 10, 24, 2), (64, 64, 8, 40, 2)])
 def test_hip_conv3x3_wgrad_vs_fp64(cin, cout, H, W, B):
     """Hand-written weight-gradient kernel (transposed LDS reads, zero-padded window image, split-K) against a float64
-    reference; includes chunks that end mid-utterance, maps narrower than a chunk, and 1x1 maps."""
+    reference; includes chunks that end mid-utterance, maps narrower than a chunk, 1x1 maps, and widths that are multiples
+    of 8 (8x8-patch chunks, with partial patches at the bottom edge)."""
     from doubleattentionspeakerverification_amd import conv
     x = torch.from_numpy(rnd(51, B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     g = torch.from_numpy(rnd(52, B, cout, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)

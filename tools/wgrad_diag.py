@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where the conv3x3 weight-gradient kernel's time goes.  Builds csrc/conv3x3_wgrad.hip four times
 (-DDASV_WGRAD_DIAG=0..2: full / producers stage the first two chunks only / no MFMA section) into tools/_diag and
-times each on the VGG4L/1024 layer shapes.  `build` cross-compiles (no GPU needed); `run` needs the GPU."""
+times each on the VGG4L/1024 layer shapes (DASV_WGRAD_RASTER=1 in the environment forces raster chunks).  `build` cross-compiles (no GPU needed); `run` needs the GPU."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIAG = os.path.join(ROOT, "tools", "_diag")
