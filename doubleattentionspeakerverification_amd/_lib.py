@@ -34,6 +34,8 @@ SIGNATURES = {
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dasv_conv3x3_bias_relu_nhwc_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -69,9 +69,12 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None):
             if part is not None and rc == 0:
                 colsum["gb"] = part.sum(dim=0)
         else:
-            rc = lib.dasv_conv3x3_bias_relu_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                                 None if bias is None else bias.data_ptr(), y.data_ptr(), B, H, W, cin, cout,
-                                                 relu, stream)
+            # small maps (single utterances): split-K over the channel slabs, partial tiles in a workspace
+            nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+            rc = lib.dasv_conv3x3_bias_relu_nhwc_ws(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                    None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                    None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, relu, stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_nhwc")
     return y
 

@@ -108,6 +108,8 @@ struct ConvParams {
     const float* bias;     // [Cout] or null
     const float* mask;     // [B,H,W,Cout] or null: outputs are zeroed where mask <= 0 (a ReLU's backward, fused)
     float* colsum;         // [mtiles][Cout] or null (window kernel): per-channel sums of the stored tile (bias gradients)
+    float* part;           // split-K (ksplit > 1): [ksplit][M][Cout] raw partial sums; bias/ReLU/mask happen in the reduction
+    int ksplit;            // window kernel: the channel slabs are divided over `ksplit` workgroups per output tile
     float* y;              // [B,H,W,Cout]
     int B, H, W, Cin, Cout;
     int M;                 // B*H*W
@@ -296,7 +298,9 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     char* Alo = Ahi + (size_t)wrows * 128;
     char* Bbase = Alo + (SPLIT ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
 
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per_split = p.tiles_per_xcd * 8;
+    const int ks = blockIdx.x / per_split, inner = blockIdx.x - ks * per_split;
+    const int xcd = inner & 7, idx = inner >> 3;
     const int tile = xcd * p.tiles_per_xcd + idx;
     if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
@@ -430,15 +434,16 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = Cin / CBK;
-    load_b(0, 0);
+    // split-K: this workgroup covers channel slabs [sl_lo, nslab) of the Cin / 64
+    const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
+    load_b(0, sl_lo * CBK);
     int it = 0;
-    for (int sl = 0; sl < nslab; ++sl) {
+    for (int sl = sl_lo; sl < nslab; ++sl) {
         const int c0 = sl * CBK;
-        if (!C1 && (DASV_CONV_DIAG != 1 || sl == 0)) load_window(c0);
-        if (DBUF && sl > 0) __syncthreads();   // every wave is done reading the previous slab's window
+        if (!C1 && (DASV_CONV_DIAG != 1 || sl == sl_lo)) load_window(c0);
+        if (DBUF && sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
         if (C1) stage_window_c1(c0);
-        else if (DASV_CONV_DIAG != 1 || sl == 0) store_window();
+        else if (DASV_CONV_DIAG != 1 || sl == sl_lo) store_window();
         for (int tap = 0; tap < 9; ++tap, ++it) {
             // DBUF: the buffer written now was last read two iterations ago, and every wave passed the barrier of
             // the previous iteration only after finishing that read -> ONE barrier per tap.
@@ -489,6 +494,19 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
         }
     }
 
+    if (p.ksplit > 1) {   // raw partial sums; conv3x3_splitk_reduce adds them up and applies bias / ReLU / mask
+        float* part = p.part + (size_t)ks * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+                if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     // epilogue: D[row = channel][col = pixel]: lane holds channels n .. n+3 of pixel m
     float* red = reinterpret_cast<float*>(smem);   // [4 wm][128 channels] partial column sums (colsum only)
     if (p.colsum != nullptr) __syncthreads();      // every wave is done with the LDS tiles
@@ -525,9 +543,47 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     }
 }
 
+// y = f(sum_ks part[ks] + bias): the second launch of a split-K convolution (fixed summation order)
+__global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias,
+                                                             const float* __restrict__ mask, float* __restrict__ y,
+                                                             long long nvec, int Cout, int S, int relu) {
+    const long long plane = nvec * 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
+        for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4*>(part + k * plane + i * 4);
+        if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % Cout));
+        if (relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (mask != nullptr) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+// split-K factor of the window kernel: when the map has too few output tiles to fill the chip (small batches), the
+// channel slabs of a tile are divided over several workgroups
+static int conv3x3_ksplit(int B, int H, int W, int Cin, int Cout) {
+    if (W > 80) return 1;
+    const long long M = (long long)B * H * W;
+    const long long tiles = ((M + WBM - 1) / WBM) * (Cout / CBN);
+    const int nslab = Cin / CBK;
+    if (tiles >= 192 || nslab < 2) return 1;
+    long long S = (256 + tiles - 1) / tiles;
+    if (S > nslab) S = nslab;
+    return (int)S;
+}
+
 }  // namespace dasv
 
 extern "C" {
+
+size_t dasv_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return 0;
+    const int S = dasv::conv3x3_ksplit(B, H, W, Cin, Cout);
+    return S > 1 ? (size_t)S * B * H * W * Cout * sizeof(float) : 0;
+}
 
 size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
@@ -555,8 +611,8 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 }
 
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
-                          const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, int B, int H, int W,
-                          int Cin, int Cout, int relu, dasv_stream_t stream) {
+                          const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
+                          size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -568,6 +624,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (colsum != nullptr && W > 80) return DASV_E_SHAPE;   // only the window kernel carries the column sums
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
     p.mel = mel; p.w1 = w1; p.b1 = b1;
+    p.part = nullptr; p.ksplit = 1;
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
     static int force_tile_kernel = -1;
@@ -579,7 +636,14 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         const size_t lds1 = (size_t)wrows * 128 * (mode == 0 ? 2 : 1) + 32768;
         const bool dbuf = mode == 0 && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
         const size_t lds = lds1 + (dbuf ? 32768 : 0);
-        const dim3 grid((unsigned)(p.tiles_per_xcd * 8)), block(512);
+        // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
+        const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
+        if (S > 1) {
+            if (workspace_bytes < (size_t)S * p.M * Cout * sizeof(float)) return DASV_E_WORKSPACE;
+            p.part = static_cast<float*>(workspace);
+            p.ksplit = S;
+        }
+        const dim3 grid((unsigned)(p.tiles_per_xcd * 8 * p.ksplit)), block(512);
 #define DASV_LAUNCH_WINDOW(SP, DB, CC)                                                                               \
         do {                                                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC>), \
@@ -597,6 +661,14 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false);
         else DASV_LAUNCH_WINDOW(2, false, false);
 #undef DASV_LAUNCH_WINDOW
+        if (p.ksplit > 1) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return (int)e;
+            const long long nvec = (long long)p.M * Cout / 4;
+            const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+            hipLaunchKernelGGL(dasv::conv3x3_splitk_reduce, dim3(blocks), dim3(256), 0, s, p.part, bias, mask, y, nvec, Cout,
+                               p.ksplit, relu);
+        }
         return (int)hipGetLastError();
     }
     p.mtiles = (p.M + dasv::CBM - 1) / dasv::CBM;
@@ -620,14 +692,22 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
 
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
-    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, B, H, W, Cin, Cout, relu, stream);
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, nullptr, 0, B, H, W, Cin, Cout,
+                          relu, stream);
+}
+
+int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu,
+                                   dasv_stream_t stream) {
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, workspace, workspace_bytes, B,
+                          H, W, Cin, Cout, relu, stream);
 }
 
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
                              float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (mask == nullptr) return DASV_E_NULL;
-    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, nullptr, mask, colsum_partial, y, B, H, W, Cin, Cout,
-                          0, stream);
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, nullptr, mask, colsum_partial, y, nullptr, 0, B, H, W,
+                          Cin, Cout, 0, stream);
 }
 
 int dasv_conv3x3_colsum_rows(int B, int H, int W) {
@@ -638,7 +718,8 @@ int dasv_conv3x3_colsum_rows(int B, int H, int W) {
 int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,
                                            const void* w_lo, const float* bias, float* y, int B, int H, int W, int Cmid,
                                            int Cout, dasv_stream_t stream) {
-    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, nullptr, nullptr, y, B, H, W, Cmid, Cout, 1, stream);
+    return conv3x3_launch(mode, nullptr, mel, w1, b1, w_hi, w_lo, bias, nullptr, nullptr, y, nullptr, 0, B, H, W, Cmid,
+                          Cout, 1, stream);
 }
 
 }  // extern "C"

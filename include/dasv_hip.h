@@ -146,6 +146,14 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+/* Same with a caller-provided workspace of dasv_conv3x3_workspace_bytes() bytes: when the map has too few output tiles to
+ * fill the chip (single utterances — getEmbeddingExample.py, the B=1 scoring loop of train.py:117-133) the channel
+ * slabs of each tile are divided over several workgroups (split-K) and a second launch sums the partial tiles in a fixed
+ * order and applies bias / ReLU.  workspace_bytes() is 0 when one pass already fills the chip (then this is the call above). */
+size_t dasv_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu,
+                                   dasv_stream_t stream);
 /* y = conv3x3(x) where mask > 0, else 0 (mask [B,H,W,Cout]).  The data gradient of `F.relu(convX2(F.relu(convX1(h))))`
  * w.r.t. convX1's pre-activation in one launch: x = gradient at convX2's output (already masked), weights = convX2's
  * transposed and flipped, mask = convX2's input (= convX1's ReLU output).  Saves autograd's threshold_backward pass.

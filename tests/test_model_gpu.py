@@ -202,10 +202,12 @@ def test_variable_length_bucketed_embeddings_equal_one_at_a_time_runs():
     assert rel16 < 2e-2
 
 
-@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 9, 7, 3), (128, 128, 33, 80, 2), (256, 512, 19, 5, 4), (128, 256, 1, 1, 1)])
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 9, 7, 3), (128, 128, 33, 80, 2), (256, 512, 19, 5, 4), (128, 256, 1, 1, 1),
+                                           (1024, 1024, 38, 10, 1), (512, 512, 75, 20, 1), (192, 128, 5, 3, 1)])
 def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
     """Hand-written implicit-GEMM conv (csrc/conv3x3.hip) against a float64 convolution: split mode is fp32-grade
-    (<= 2e-5 of the output scale), bf16 mode is stated (<= 1e-2); includes image borders, M tails and 1x1 maps."""
+    (<= 2e-5 of the output scale), bf16 mode is stated (<= 1e-2); includes image borders, M tails, 1x1 maps and the
+    single-utterance shapes that take the split-K path (channel slabs divided over workgroups, 3 slabs over 3 included)."""
     from doubleattentionspeakerverification_amd import conv
     x = torch.from_numpy(rnd(1, B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
@@ -439,8 +441,8 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     """All gradients of the VGG4L front-end through the HIP path — convs, pools, conv11, with the ReLU masks fused into
     the neighbouring backward kernels.  kernel_size 512 mixes HIP and MIOpen layers (conv12 has 64 output channels),
     which exercises the fusion protocol's fallbacks.  Three checks:
-      (a) fused and unfused HIP backward are bit-identical (same forward, so no arg-max / ReLU-sign flips) — bias gradients
-          to 2e-6, since the fused path takes them from the epilogues' per-workgroup column sums;
+      (a) fused and unfused HIP backward agree to 2e-5 (same forward, so no arg-max / ReLU-sign flips; only summation orders
+          differ);
       (b) every HIP conv layer's weight/bias gradient equals ATen's convolution_backward on the SAME saved tensors;
       (c) against PyTorch-ROCm's own path the gradient vectors agree in direction (a single arg-max flip caused by the
           5e-6 forward difference moves one pixel's gradient — percent-level for one channel in a 2-utterance batch —
@@ -488,10 +490,10 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
             assert float((conv_.weight.grad - gw).abs().max()) <= 2e-5 * float(gw.abs().max()), name
             assert float((conv_.bias.grad - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), name
     for k in grads["torch"]:
-        if ks == 1024 and not k.endswith(".bias"):                                                             # (a)
-            assert torch.equal(grads["fused"][k], grads["unfused"][k]), k
-        elif ks == 1024:   # bias gradients: fused path sums per-workgroup partials from the kernel epilogues (other order)
-            assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 2e-6 * float(grads["unfused"][k].abs().max()), k
+        if ks == 1024:                                                                                         # (a)
+            # same forward, so no arg-max / ReLU-sign flips: only summation orders differ (bias gradients from the
+            # epilogues' per-workgroup partial sums; split-K data gradients on this small map in the unfused path)
+            assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 2e-5 * float(grads["unfused"][k].abs().max()), k
         else:   # below a MIOpen layer (conv12 at this width) the backward is not run-to-run deterministic
             assert float((grads["fused"][k] - grads["unfused"][k]).abs().max()) <= 1e-5 * float(grads["unfused"][k].abs().max()), k
         cosv = float(torch.nn.functional.cosine_similarity(grads["fused"][k].flatten().double(),
