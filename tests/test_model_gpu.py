@@ -567,3 +567,39 @@ def test_vgg3l_default_width_and_long_utterance_on_the_hip_path():
     gw_ref = torch.ops.aten.convolution_backward(g, a, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     gw = conv.conv3x3_wgrad(a, g, "split")
     assert float((gw - gw_ref).abs().max()) <= 5e-5 * float(gw_ref.abs().max())
+
+
+def test_embedding_graph_replays_the_eager_result_and_cuts_single_utterance_latency():
+    """hipGraph capture of getEmbedding at B=1 (the reference's one-utterance flows): same embedding as the eager path,
+    for different inputs through the same graph; latency of both reported."""
+    import time
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.graphs import EmbeddingGraph
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=100, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(3)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).eval()
+    xs = [torch.from_numpy(rnd(90 + i, 1, 297, 80)).to(DEV) for i in range(3)]
+    with torch.no_grad():
+        ref = [net.getEmbedding(x).clone() for x in xs]
+    g = EmbeddingGraph(net, 1, 297)
+    for x, r in zip(xs, ref):
+        out = g(x)
+        assert out.shape == r.shape and float((out - r).abs().max()) <= 1e-6 * float(r.abs().max())
+    with pytest.raises(ValueError):
+        g(torch.zeros(2, 297, 80, device=DEV))
+
+    def timeit(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        eager = timeit(lambda: net.getEmbedding(xs[0]))
+    graph = timeit(lambda: g(xs[0]))
+    print("single-utterance getEmbedding: eager %.3f ms, hipGraph replay %.3f ms" % (eager, graph))
+    assert graph < eager * 1.05
