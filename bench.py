@@ -176,7 +176,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train"])
+    ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train", "varlen"])
+    ap.add_argument("--utterances", type=int, default=1024, help="varlen: utterances per rank and step")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=300)
@@ -255,7 +256,23 @@ def main():
         pool_shape = (B, Tp, 5120, 32)
         esize = 4 if compute_dtype == torch.float32 else 2
         with_align = False
-        if args.workload == "embed":
+        if args.workload == "varlen":
+            # BASELINE config 5: utterances of T in [150, 800] frames, packed into equal-length buckets (the only packing
+            # that is exact for this model: no padding anywhere, batching.py), this rank's share resident in HBM
+            from doubleattentionspeakerverification_amd.batching import embed_utterances
+            net.eval()
+            lens = rs.randint(150, 801, size=args.utterances)
+            utts = [torch.from_numpy((2.0 * rs.standard_normal((int(n), 80))).astype(np.float32)).to(dev) for n in lens]
+            utts = [u - u.mean(dim=0, keepdim=True) for u in utts]
+            B = args.utterances
+
+            def step(i):
+                return embed_utterances(net, utts, max_batch=args.batch)
+            config = {"workload": "variable-length embedding extraction: %d utterances per GPU and step, T uniform in [150,800], "
+                                  "equal-length buckets of up to %d (BASELINE config 5), VGG4L/1024 + DoubleMHA" % (B, args.batch),
+                      "global_batch": B * world, "frames": "150..800 (mean %.0f)" % float(np.mean(lens)),
+                      "parallelism": "replicas x%d (no data exchange)" % world, "conv": args.conv}
+        elif args.workload == "embed":
             net.eval()
 
             def step(i):
