@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train", "varlen"])
     ap.add_argument("--utterances", type=int, default=1024, help="varlen: utterances per rank and step")
+    ap.add_argument("--packing", default="ragged", choices=["ragged", "bucket"],
+                    help="varlen: ragged = utterances stacked along time, borders from tables (ragged.py); bucket = "
+                         "equal-length buckets (batching.py)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=300)
@@ -260,6 +263,7 @@ def main():
             # BASELINE config 5: utterances of T in [150, 800] frames, packed into equal-length buckets (the only packing
             # that is exact for this model: no padding anywhere, batching.py), this rank's share resident in HBM
             from doubleattentionspeakerverification_amd.batching import embed_utterances
+            from doubleattentionspeakerverification_amd.ragged import embed_ragged_batches
             net.eval()
             lens = rs.randint(150, 801, size=args.utterances)
             utts = [torch.from_numpy((2.0 * rs.standard_normal((int(n), 80))).astype(np.float32)).to(dev) for n in lens]
@@ -267,9 +271,13 @@ def main():
             B = args.utterances
 
             def step(i):
+                if args.packing == "ragged":
+                    return embed_ragged_batches(net, utts, max_frames=args.batch * 300)
                 return embed_utterances(net, utts, max_batch=args.batch)
             config = {"workload": "variable-length embedding extraction: %d utterances per GPU and step, T uniform in [150,800], "
-                                  "equal-length buckets of up to %d (BASELINE config 5), VGG4L/1024 + DoubleMHA" % (B, args.batch),
+                                  "%s (BASELINE config 5), VGG4L/1024 + DoubleMHA"
+                                  % (B, "stacked along time in groups of <= %d frames, utterance borders from tables" % (args.batch * 300)
+                                     if args.packing == "ragged" else "equal-length buckets of up to %d" % args.batch),
                       "global_batch": B * world, "frames": "150..800 (mean %.0f)" % float(np.mean(lens)),
                       "parallelism": "replicas x%d (no data exchange)" % world, "conv": args.conv}
         elif args.workload == "embed":

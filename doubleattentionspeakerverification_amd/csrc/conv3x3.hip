@@ -108,6 +108,8 @@ struct ConvParams {
     const float* bias;     // [Cout] or null
     const float* mask;     // [B,H,W,Cout] or null: outputs are zeroed where mask <= 0 (a ReLU's backward, fused)
     float* colsum;         // [mtiles][Cout] or null (window kernel): per-channel sums of the stored tile (bias gradients)
+    const int* row_span;   // ragged batch (B == 1, H == total rows): [H][2] = first / one-past-last row of the utterance
+                           // that owns each row; image borders come from this table instead of row % H
     float* part;           // split-K (ksplit > 1): [ksplit][M][Cout] raw partial sums; bias/ReLU/mask happen in the reduction
     int ksplit;            // window kernel: the channel slabs are divided over `ksplit` workgroups per output tile
     float* y;              // [B,H,W,Cout]
@@ -316,11 +318,17 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
         const int m = m0 + wm * 64 + i * 16 + frow;
         unsigned mask = 0;
         if (m < p.M) {
-            const int w_ = m % W, h_ = (m / W) % H;
+            const int w_ = m % W;
+            int h_ = (m / W) % H, hend = H;
+            if (p.row_span != nullptr) {      // ragged: row m / W belongs to the utterance spanning rows [lo, hi)
+                const int r = m / W, lo = p.row_span[2 * r];
+                h_ = r - lo;
+                hend = p.row_span[2 * r + 1] - lo;
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
-                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
+                if ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
             }
         }
         amask[i] = mask;
@@ -612,11 +620,12 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
-                          size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
+                          size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
+                          const int* row_span = nullptr) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
-    if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0 || H > 32767 || W > 65535) return DASV_E_SHAPE;
+    if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return DASV_E_SHAPE;
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
     if (mode < 0 || mode > 2) return DASV_E_DTYPE;
     dasv::ConvParams p;
@@ -625,11 +634,13 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
     p.mel = mel; p.w1 = w1; p.b1 = b1;
     p.part = nullptr; p.ksplit = 1;
+    p.row_span = row_span;
+    if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
     static int force_tile_kernel = -1;
     if (force_tile_kernel < 0) force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;
-    if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr)) {
+    if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr || row_span != nullptr)) {
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
@@ -701,6 +712,14 @@ int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, c
                                    dasv_stream_t stream) {
     return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, workspace, workspace_bytes, B,
                           H, W, Cin, Cout, relu, stream);
+}
+
+int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                       const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,
+                                       int Cout, int relu, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, workspace, workspace_bytes, 1,
+                          rows, W, Cin, Cout, relu, stream, row_span);
 }
 
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,

@@ -13,7 +13,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // x [B,H,W] (one channel), w [Cout,1,3,3], y [B,H,W,Cout]
 __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         int H, int W, int Cout, long long npix, int relu) {
+                                                         int H, int W, int Cout, long long npix, int relu,
+                                                         const int* __restrict__ row_span) {
     const int quads = Cout >> 2;                 // lanes per pixel
     const int ppb = blockDim.x / quads;          // pixels per block iteration
     const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
@@ -27,12 +28,18 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         if (bias != nullptr) bv[c] = bias[q * 4 + c];
     }
     for (long long pix = (long long)blockIdx.x * ppb + pl; pix < npix; pix += (long long)gridDim.x * ppb) {
-        const int w_ = (int)(pix % W), h_ = (int)((pix / W) % H);
+        const int w_ = (int)(pix % W);
+        int h_ = (int)((pix / W) % H), hend = H;
+        if (row_span != nullptr) {   // ragged batch: image borders from the row table
+            const int r = (int)(pix / W), lo = row_span[2 * r];
+            h_ = r - lo;
+            hend = row_span[2 * r + 1] - lo;
+        }
         float in[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-            in[t] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? x[pix + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+            in[t] = ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) ? x[pix + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
         }
         f4 o = bv;
 #pragma unroll
@@ -48,18 +55,23 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
 }
 
 // x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = ceil(H/2), Wo = ceil(W/2); windows clipped at the bottom/right edge (ceil_mode)
+// ragged batch (pool_src != null): B == 1, Ho = total output rows; pool_src[ro] = {first input row, 1 if the window has a second row}
 __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              int H, int W, int C, int Ho, int Wo, long long nvec) {
+                                                              int H, int W, int C, int Ho, int Wo, long long nvec,
+                                                              const int* __restrict__ pool_src) {
     const int cq = C >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
         const long long op = i / cq;
         const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
         const long long b = op / ((long long)Wo * Ho);
-        const int h0 = 2 * ho, w0 = 2 * wo;
+        int h0 = 2 * ho;
+        const int w0 = 2 * wo;
+        bool hh = h0 + 1 < H;
+        if (pool_src != nullptr) { h0 = pool_src[2 * ho]; hh = pool_src[2 * ho + 1] != 0; }
         const float* base = x + (((size_t)b * H + h0) * W + w0) * C + q * 4;
         f4 m = *reinterpret_cast<const f4*>(base);
-        const bool hw = w0 + 1 < W, hh = h0 + 1 < H;
+        const bool hw = w0 + 1 < W;
         if (hw) { const f4 v = *reinterpret_cast<const f4*>(base + C); m = __builtin_elementwise_max(m, v); }
         if (hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C); m = __builtin_elementwise_max(m, v); }
         if (hw && hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C + C); m = __builtin_elementwise_max(m, v); }
@@ -194,8 +206,8 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __rest
 
 extern "C" {
 
-int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
-                                   int Cout, int relu, dasv_stream_t stream) {
+static int c1_launch(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cout, int relu,
+                     const int* row_span, dasv_stream_t stream) {
     if (x == nullptr || w == nullptr || y == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
@@ -203,8 +215,19 @@ int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* 
     long long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W,
-                       Cout, npix, relu);
+                       Cout, npix, relu, row_span);
     return (int)hipGetLastError();
+}
+
+int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                                   int Cout, int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, y, B, H, W, Cout, relu, nullptr, stream);
+}
+
+int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, const int* row_span,
+                                          int rows, int W, int Cout, int relu, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return c1_launch(x, w, bias, y, 1, rows, W, Cout, relu, row_span, stream);
 }
 
 int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream) {
@@ -214,7 +237,21 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo, nvec);
+    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo,
+                       nvec, static_cast<const int*>(nullptr));
+    return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_src, int rows_in, int rows_out, int W, int C,
+                                     dasv_stream_t stream) {
+    if (x == nullptr || y == nullptr || pool_src == nullptr) return DASV_E_NULL;
+    if (rows_in <= 0 || rows_out <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
+    const int Wo = (W + 1) / 2;
+    const long long nvec = (long long)rows_out * Wo * (C / 4);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows_in, W, C,
+                       rows_out, Wo, nvec, pool_src);
     return (int)hipGetLastError();
 }
 

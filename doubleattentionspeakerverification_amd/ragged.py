@@ -1,0 +1,172 @@
+"""Ragged batches: utterances of DIFFERENT lengths through the front-end in ONE set of launches (inference).
+
+The reference can only run unequal utterances one per forward (train.py:117-133): there are no padding masks anywhere in
+the model, so zero-padding a batch changes the result.  But the convolutions and the pools are position-independent
+except at the utterance borders.  Here the utterances are stacked along the time axis into one tall NHWC image
+[sum T_i, 80, C]; the kernels take the borders from small integer tables (`dasv_*_ragged_nhwc`, include/dasv_hip.h):
+a conv tap that would cross into the neighbouring utterance reads zero, exactly as at the top/bottom of a single image,
+and the ceil-mode pool of an odd-length utterance clips its last window.  Every output pixel sees the same operands in
+the same order as in a one-utterance forward, so the embeddings equal the B=1 results (up to the split-K summation
+order of small maps) while the launches are as large as a full batch — no per-length buckets.
+
+`embed_ragged(net, utterances)` -> [len(utterances), emb] for a SpeakerClassifier with a VGG front-end; the pooling runs
+on a zero-padded [B, T'max, D] copy of the (small) front-end output with per-utterance `lengths`.
+"""
+import torch
+
+from . import _lib
+from . import conv as _conv
+from . import poolings as _pool
+
+__all__ = ["embed_ragged", "embed_ragged_batches", "ragged_tables", "front_end_ragged"]
+
+
+def ragged_tables(lengths, levels, device):
+    """Border tables for `levels` conv blocks.  Returns (spans, pools, lens): spans[l] int32 [rows_l, 2] (first row, one
+    past the last row of the owning utterance) for the maps entering block l; pools[l] int32 [rows_{l+1}, 2] (first input
+    row, has-second-row) of the pool that closes block l; lens[l] the utterance lengths at level l as a Python list
+    (lens[levels] = output lengths)."""
+    spans, pools, lens = [], [], []
+    cur_host = [int(n) for n in lengths]
+    if not cur_host or min(cur_host) <= 0:
+        raise ValueError("lengths must be a non-empty list of positive frame counts")
+    # one tiny host->device copy (the lengths); everything else is computed on the device with known output sizes, so
+    # there is no synchronisation and no large pageable copy (those cost milliseconds each)
+    cur = torch.tensor(cur_host, dtype=torch.int64).to(device)
+    ids = torch.arange(len(cur_host), device=device)
+    for _ in range(levels):
+        lens.append(cur_host)
+        rows = sum(cur_host)
+        start = torch.cumsum(cur, 0) - cur
+        owner = torch.repeat_interleave(ids, cur, output_size=rows)
+        spans.append(torch.stack([start[owner], (start + cur)[owner]], dim=1).to(torch.int32))
+        nxt_host = [(n + 1) // 2 for n in cur_host]
+        nxt = (cur + 1) // 2
+        orows = sum(nxt_host)
+        ostart = torch.cumsum(nxt, 0) - nxt
+        oowner = torch.repeat_interleave(ids, nxt, output_size=orows)
+        local = torch.arange(orows, device=device) - ostart[oowner]       # output row inside its utterance
+        first = start[oowner] + 2 * local
+        second = (2 * local + 1 < cur[oowner]).to(torch.int64)
+        pools.append(torch.stack([first, second], dim=1).to(torch.int32))
+        cur, cur_host = nxt, nxt_host
+    lens.append(cur_host)
+    return spans, pools, lens
+
+
+def _conv_ragged(x, conv, packed, mode, span):
+    """x [rows, W, Cin] NHWC fp32 -> relu(conv3x3(x) + bias) [rows, W, Cout] with utterance borders from `span`."""
+    lib = _lib.load()
+    rows, W, cin = x.shape
+    cout = conv.out_channels
+    hi, lo = packed.get(conv.weight, mode)
+    y = torch.empty((rows, W, cout), dtype=torch.float32, device=x.device)
+    nws = lib.dasv_conv3x3_workspace_bytes(1, rows, W, cin, cout)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_bias_relu_ragged_nhwc(
+            _conv.MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
+            y.data_ptr(), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin, cout, 1,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_nhwc")
+    return y
+
+
+@torch.no_grad()
+def front_end_ragged(front, utterances, mode=None):
+    """VGG front-end over stacked utterances.  Returns (frames [sum T'_i, D] with the reference's feature order c*F'+f,
+    lengths T'_i as a list)."""
+    lib = _lib.load()
+    dev = next(front.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("the ragged front-end runs on the GPU only (libdasv_hip.so); no CPU fallback")
+    mode = mode or front.conv_mode
+    if mode == "torch":
+        raise RuntimeError("the ragged path needs the HIP convolutions (conv_mode split / bf16 / fp16)")
+    x = torch.cat([u.to(dev, torch.float32) for u in utterances], dim=0).contiguous()        # [rows, 80]
+    W = x.shape[1]
+    spans, pools, lens = ragged_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    h = None
+    for blk in range(1, front.n_blocks + 1):
+        span = spans[blk - 1]
+        for name in ("conv%d1" % blk, "conv%d2" % blk):
+            conv = getattr(front, name)
+            if conv.in_channels == 1:
+                rows = x.shape[0]
+                h = torch.empty((rows, W, conv.out_channels), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(
+                        x.data_ptr(), conv.weight.detach().contiguous().data_ptr(),
+                        None if conv.bias is None else conv.bias.detach().data_ptr(), h.data_ptr(), span.data_ptr(), rows, W,
+                        conv.out_channels, 1, stream)
+                _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
+            else:
+                if not _conv.supported(conv.in_channels, conv.out_channels):
+                    raise RuntimeError("ragged front-end: layer %s (%d -> %d channels) is outside the HIP kernel's shapes"
+                                       % (name, conv.in_channels, conv.out_channels))
+                key = (name, dev.index)
+                packed = front._packed.get(key)
+                if packed is None:
+                    packed = front._packed[key] = _conv.PackedConvWeights()
+                h = _conv_ragged(h, conv, packed, mode, span)
+        rows_in, rows_out = h.shape[0], pools[blk - 1].shape[0]
+        Wo = (W + 1) // 2
+        y = torch.empty((rows_out, Wo, h.shape[2]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dasv_maxpool2x2_ceil_ragged_nhwc(h.data_ptr(), y.data_ptr(), pools[blk - 1].data_ptr(), rows_in, rows_out, W,
+                                                      h.shape[2], stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_ragged_nhwc")
+        h, W = y, Wo
+    # [rows, F', C] -> [rows, C*F'] with feature = c*F' + f (CNNs.py:49-50 / 88-89)
+    frames = h.permute(0, 2, 1).reshape(h.shape[0], h.shape[2] * h.shape[1])
+    return frames, list(lens[-1])
+
+
+@torch.no_grad()
+def embed_ragged(net, utterances, mode=None):
+    """Embeddings [len(utterances), emb] of utterances with arbitrary (different) frame counts, one set of launches."""
+    if net.training:
+        raise RuntimeError("embed_ragged is an inference path: call net.eval() first")
+    frames, tl = front_end_ragged(net.front_end, utterances, mode)
+    B, tmax, D = len(tl), max(tl), frames.shape[1]
+    padded = frames.new_zeros((B, tmax, D))
+    lens64 = torch.tensor(tl, dtype=torch.int64).to(frames.device)
+    owner = torch.repeat_interleave(torch.arange(B, device=frames.device), lens64, output_size=frames.shape[0])
+    start = torch.cumsum(lens64, 0) - lens64
+    local = torch.arange(frames.shape[0], device=frames.device) - start[owner]
+    padded[owner, local] = frames
+    lengths = lens64.to(torch.int32)
+    pool = net.poolingLayer
+    if isinstance(pool, _pool.DoubleMHA):
+        vec = pool.pool(padded, lengths=lengths)
+    elif isinstance(pool, (_pool.MultiHeadAttention, _pool.Attention)):
+        vec = pool(padded, lengths=lengths)[0]
+    else:
+        raise RuntimeError("unsupported pooling layer %r" % type(pool).__name__)
+    hidden = torch.relu(net.fc1(vec))
+    return net.b2(torch.relu(net.fc2(hidden)))
+
+
+@torch.no_grad()
+def embed_ragged_batches(net, utterances, max_frames=64 * 300, mode=None, rank=0, world=1):
+    """Embeddings of many utterances of arbitrary lengths: greedy groups of up to `max_frames` total frames (the footprint
+    of a [64,300,80] batch by default), each group one ragged pass.  Returns {index: embedding} for the groups this rank
+    owns (round-robin over `world` ranks; all of them when world == 1)."""
+    order = sorted(range(len(utterances)), key=lambda i: -int(utterances[i].shape[0]))   # similar lengths share a group
+    groups, cur, frames = [], [], 0
+    for i in order:
+        n = int(utterances[i].shape[0])
+        if cur and frames + n > max_frames:
+            groups.append(cur)
+            cur, frames = [], 0
+        cur.append(i)
+        frames += n
+    if cur:
+        groups.append(cur)
+    out = {}
+    for g in groups[rank::world]:
+        emb = embed_ragged(net, [utterances[i] for i in g], mode)
+        for j, i in enumerate(g):
+            out[i] = emb[j]
+    return out

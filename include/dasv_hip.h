@@ -189,6 +189,24 @@ int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* 
  * `F.max_pool2d(x, 2, stride=2, ceil_mode=True)` (CNNs.py:40,44,48 / 74,78,82,86).  C % 4 == 0. */
 int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Ragged batches (inference): utterances of DIFFERENT lengths processed as one tall image.  The reference can only run
+ * unequal utterances one per forward (train.py:117-133); zero-padding them into a batch is not equivalent (no masks
+ * anywhere in the model), but the convolutions and pools are position-independent except at the utterance borders, so the
+ * utterances are stacked along the time axis ([rows = sum T_i, W, C], NHWC) and the kernels take the borders from tables:
+ *   row_span [rows][2] int32: first row and one-past-last row of the utterance that owns each row;
+ *   pool_src [rows_out][2] int32: for each output row of the ceil-mode pool, its first input row and whether a second
+ *                                 input row exists (it does not for the last row of an odd-length utterance).
+ * Results equal the one-utterance-per-forward results (same arithmetic per output pixel).
+ * ------------------------------------------------------------------------ */
+int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
+                                       const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,
+                                       int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, const int* row_span,
+                                          int rows, int W, int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_src, int rows_in, int rows_out, int W, int C,
+                                     dasv_stream_t stream);
+
 /* Backward of the max-pool above: gx [B,H,W,C] (OVERWRITTEN) from x [B,H,W,C] and gy [B,ceil(H/2),ceil(W/2),C]; the
  * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d
  * backward for CNNs.py:40,44,48 / 74,78,82,86. */

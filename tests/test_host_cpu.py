@@ -185,3 +185,30 @@ def test_utils_helpers_match_reference_vectors(tmp_path):
     lab = tmp_path / "labels.ndx"
     lab.write_text("a/1 spk1 0\nb/2 spk2 1\nc/3 spk1 0\n")
     assert utils.getNumberOfSpeakers(str(lab)) == 2
+
+
+def test_ragged_tables_match_a_naive_walk():
+    """Border tables of the ragged path (ragged.py): every row knows its utterance's span, every pooled row its two source
+    rows, and lengths halve with ceil at every level."""
+    from doubleattentionspeakerverification_amd.ragged import ragged_tables
+    lengths = [5, 2, 3, 1, 8]
+    spans, pools, lens = ragged_tables(lengths, 3, "cpu")
+    cur = list(lengths)
+    for lvl in range(3):
+        assert list(lens[lvl]) == cur
+        rows, start = [], 0
+        for n in cur:
+            rows += [[start, start + n]] * n
+            start += n
+        assert spans[lvl].tolist() == rows
+        src, start = [], 0
+        for n in cur:
+            for o in range((n + 1) // 2):
+                src.append([start + 2 * o, 1 if 2 * o + 1 < n else 0])
+            start += n
+        assert pools[lvl].tolist() == src
+        cur = [(n + 1) // 2 for n in cur]
+    assert list(lens[3]) == cur
+    import pytest
+    with pytest.raises(ValueError):
+        ragged_tables([3, 0], 2, "cpu")

@@ -603,3 +603,39 @@ def test_embedding_graph_replays_the_eager_result_and_cuts_single_utterance_late
     graph = timeit(lambda: g(xs[0]))
     print("single-utterance getEmbedding: eager %.3f ms, hipGraph replay %.3f ms" % (eager, graph))
     assert graph < eager * 1.05
+
+
+def test_ragged_batch_equals_one_utterance_per_forward():
+    """Utterances of different lengths stacked along time and run as ONE set of launches (ragged.py) against the
+    reference's only exact way to handle them: one utterance per forward (train.py:117-133).  Odd lengths exercise the
+    clipped ceil-mode pool windows at every level, and neighbouring utterances must not leak through the 3x3 taps."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.ragged import embed_ragged, front_end_ragged
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=50, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(21)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).eval()
+    lens = [150, 297, 301, 163, 800, 151, 17, 1]
+    utts = [torch.from_numpy(rnd(100 + i, n, 80)).to(DEV) for i, n in enumerate(lens)]
+    with torch.no_grad():
+        ref_frames = [net.front_end(u.unsqueeze(0))[0] for u in utts]
+        ref = torch.cat([net.getEmbedding(u.unsqueeze(0)) for u in utts])
+    frames, tl = front_end_ragged(net.front_end, utts)
+    assert tl == [f.shape[0] for f in ref_frames] and frames.shape == (sum(tl), 5120)
+    off = 0
+    for f, n in zip(ref_frames, tl):
+        got = frames[off:off + n]
+        assert float((got - f).abs().max()) <= 2e-5 * float(f.abs().max()) + 1e-7
+        off += n
+    emb = embed_ragged(net, utts)
+    assert emb.shape == ref.shape
+    assert float((emb - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # the other pooling heads take the same path
+    for method in ("MHA", "Attention"):
+        p2 = argparse.Namespace(**{**vars(p), "pooling_method": method, "heads_number": 8})
+        torch.manual_seed(22)
+        net2 = SpeakerClassifier(p2, torch.device(DEV)).to(DEV).eval()
+        with torch.no_grad():
+            r2 = torch.cat([net2.getEmbedding(u.unsqueeze(0)) for u in utts[:4]])
+        e2 = embed_ragged(net2, utts[:4])
+        assert float((e2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), method
