@@ -351,7 +351,8 @@ def main():
             mult = 3 if args.conv == "split" else 1
             roofline = {"kernel": "dasv::conv3x3_window_kernel (implicit-GEMM conv3x3+bias+ReLU, %s operands)" % args.conv,
                         "bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
-                        "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4), "traffic": None,
+                        "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
+                        "traffic": pmc_traffic("embed_conv", "split") if args.conv == "split" and args.workload == "embed" else None,
                         "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
                         "launches_per_step": len(ctimer.rec) // max(1, args.steps),
                         "mfma_flops_executed_per_algorithmic_flop": mult,
