@@ -109,9 +109,10 @@ for run in ("pool", "embed"):
             traffic["embed_conv_split"] = {"kernel": "dasv::conv3x3_window_kernel<0,..>", "fetch_bytes_x2": cf, "write_bytes": cw,
                                            "hbm_bytes_per_launch": int(cf + cw), "algorithmic_bytes_per_launch": int(calg)}
             md.append("* conv PMC per launch (average over the seven layers): FETCH_SIZE x2 = %.1f MB, WRITE_SIZE = %.1f MB -> HBM "
-                      "traffic %.1f MB vs %.1f MB algorithmic (x + y + both weight planes once): x%.2f — writes are exact; part of the "
-                      "input re-reads (window halo, one pass per 128-channel output tile) reaches HBM.  At ~1 TB/s average the "
-                      "kernel stays MFMA-bound\n"
+                      "traffic %.1f MB vs %.1f MB algorithmic (x + y + both weight planes once): x%.2f.  Writes are exact.  The counters "
+                      "sit on the L2's fabric side and include Infinity-Cache hits (MI355X_MICROARCH.md): the excess reads are the "
+                      "weight planes (up to 37.7 MB for conv42, resident in the 256 MiB Infinity Cache) streamed once per XCD and "
+                      "per round of workgroups, plus the window halo.  At ~1 TB/s average the kernel stays MFMA-bound\n"
                       % (cf / 1e6, cw / 1e6, (cf + cw) / 1e6, calg / 1e6, (cf + cw) / calg))
     if bl:
         pr = bl.get("roofline_pooling") or bl["roofline"]
