@@ -190,13 +190,17 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __rest
     }
 }
 
+// 16 lanes per output value: lane j sums partial rows j, j+16, ... (fixed order), then a DPP butterfly over the 16 lanes —
+// deterministic, and a few thousand partial rows cost microseconds instead of one long serial loop per thread
 __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __restrict__ part, float* __restrict__ gw,
                                                              float* __restrict__ gb, int nblk, int Cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (n, t) with t in 0..9
-    if (i >= Cout * 10) return;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // (n, t) with t in 0..9
+    const int j = threadIdx.x & 15;
     float v = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < nblk; ++k) v += part[(size_t)k * Cout * 10 + i];
+    if (i < Cout * 10)
+        for (int k = j; k < nblk; k += 16) v += part[(size_t)k * Cout * 10 + i];
+    v = group_sum<16>(v);
+    if (i >= Cout * 10 || j != 0) return;
     const int n = i / 10, t = i - n * 10;
     if (t < 9) gw[n * 9 + t] = v;
     else if (gb != nullptr) gb[n] = v;
@@ -290,7 +294,7 @@ int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C) {
 
 size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-    return (size_t)512 * Cout * 10 * sizeof(float);
+    return (size_t)2048 * Cout * 10 * sizeof(float);
 }
 
 int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
@@ -300,7 +304,7 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
     if (workspace_bytes < dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, Cout)) return DASV_E_WORKSPACE;
     const long long npix = (long long)B * H * W;
     const int ppb = 256 / (Cout / 4);
-    int nblk = (int)((npix + ppb - 1) / ppb < 512 ? (npix + ppb - 1) / ppb : 512);   // few partial rows: the second launch is serial in them
+    int nblk = (int)((npix + ppb - 1) / ppb < 2048 ? (npix + ppb - 1) / ppb : 2048);
     const int pix_per_block = (int)((npix + nblk - 1) / nblk);
     nblk = (int)((npix + pix_per_block - 1) / pix_per_block);
     const size_t lds = (size_t)ppb * Cout * 10 * sizeof(float);
@@ -311,7 +315,7 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
                        pix_per_block);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 + 255) / 256)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 * 16 + 255) / 256)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
     return (int)hipGetLastError();
 }
 
