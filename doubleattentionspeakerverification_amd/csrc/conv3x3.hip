@@ -40,7 +40,10 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;   // inputs are finite activations/weights
 }
-// (a, b) -> packed bf16 pairs hi = bf16(v) and lo = bf16(v - hi); plain casts lower to v_cvt_pk_bf16_f32 (RNE)
+// (a, b) -> packed bf16 pairs hi = bf16(v) and lo = bf16(v - hi); plain casts lower to v_cvt_pk_bf16_f32 (RNE).  The
+// subtraction compiles to one v_pk_add_f32; forcing two scalar v_sub_f32 (a 7 % win in the weight-gradient kernel, whose
+// staging waves share a SIMD with MFMA waves) was measured here too, interleaved in one run: 1.7 % slower — staging in this
+// kernel never runs beside MFMAs.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {

@@ -20,6 +20,27 @@ def build():
                                "-DDASV_WGRAD_DIAG=%d" % (n % 10), "-DDASV_WGRAD_NOPK=%d" % (1 - n // 10), SRC, "-o", so(n)])
 
 
+def time_round_robin(gos, rounds=3, reps=4):
+    """Best-of-`rounds` average launch time per variant, variants interleaved (clock ramps and box-to-box differences hit
+    every variant alike), after a warm-up burst that brings the clocks up."""
+    import torch
+    for _ in range(3):
+        for go in gos.values():
+            go()
+    torch.cuda.synchronize()
+    best = {n: float("inf") for n in gos}
+    for _ in range(rounds):
+        for n, go in gos.items():
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                go()
+            e.record()
+            torch.cuda.synchronize()
+            best[n] = min(best[n], s.elapsed_time(e) / reps)
+    return best
+
+
 def run():
     import torch
     dev = torch.device("cuda:0")
@@ -40,26 +61,20 @@ def run():
         g = torch.randn(B, cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         gw = torch.empty(cout, cin, 3, 3, device=dev)
         line = "%s %4d->%4d %3dx%2d |" % (name, cin, cout, H, W)
+        gos = {}
         for n, lib in libs.items():
             nb = lib.dasv_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
             ws = torch.empty(nb, dtype=torch.uint8, device=dev)
             st = torch.cuda.current_stream().cuda_stream
 
-            def go():
+            def go(lib=lib, ws=ws, nb=nb):
                 rc = lib.dasv_conv3x3_wgrad_nhwc(0, x.data_ptr(), g.data_ptr(), gw.data_ptr(), ws.data_ptr(), nb, B, H, W, cin, cout, st)
                 assert rc == 0, rc
-            for _ in range(2):
-                go()
-            torch.cuda.synchronize()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(4):
-                go()
-            e.record()
-            torch.cuda.synchronize()
-            t = s.elapsed_time(e) / 4
-            tot[n] += t
-            line += " %s %6.3f ms |" % (NAMES[n], t)
+            gos[n] = go
+        best = time_round_robin(gos)
+        for n in NAMES:
+            tot[n] += best[n]
+            line += " %s %6.3f ms |" % (NAMES[n], best[n])
         print(line, flush=True)
     print("total: " + " | ".join("%s %.2f ms" % (NAMES[n], tot[n]) for n in NAMES))
 
