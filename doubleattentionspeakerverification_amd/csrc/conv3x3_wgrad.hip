@@ -36,6 +36,9 @@ constexpr int WKC = 64;   // pixels per K chunk
 #define DASV_WGRAD_DIAG 0
 #endif
 
+#ifndef DASV_WGRAD_XCD
+#define DASV_WGRAD_XCD 1    // XCD-aware (split, tile) order: 6.53 -> 6.47 ms (interleaved A/B, tools/wgrad_diag.py)
+#endif
 #ifndef DASV_WGRAD_NOPK
 #define DASV_WGRAD_NOPK 1   // measured in one run (tools/wgrad_diag.py, "packed subs"): 7.33 ms with v_pk_add_f32, 6.79 ms without
 #endif
@@ -116,7 +119,18 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
     constexpr size_t xplane = (size_t)(16 * NX) * 128;
 
     const int tiles = p.ntiles * p.ctiles;
+#if DASV_WGRAD_XCD
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so the `tiles` workgroups that walk the SAME pixel
+    // range (one g chunk is used by every input-channel tile, one x window by every output-channel tile) are given
+    // consecutive slots of ONE XCD and share its L2
+    const int per_xcd = (tiles * p.S + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int linear = xcd * per_xcd + slot;            // split-major: an XCD owns a contiguous range of (split, tile)
+    if (slot >= per_xcd || linear >= tiles * p.S) return;
+    const int split = linear / tiles, tile = linear - split * tiles;
+#else
     const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+#endif
     const int n0 = (tile / p.ctiles) * 64, c0 = (tile % p.ctiles) * 64;
     const int chunk_lo = split * p.chunks_per_split;
     const int total_chunks = p.B * p.chunks_per_image;
@@ -282,6 +296,7 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
     }
 
     // ---------------------------------------------------------------------- consumers
+    // (s_setprio 3 for these waves against the staging wave on their SIMD was measured: no change)
     const int lane = tid & 63, wv = tid >> 6;   // wave = input-channel block
     const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     f32x4 acc[4][9];
@@ -406,7 +421,7 @@ int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw,
     // two buffers; both planes are always carved (the bf16 mode simply leaves the lo planes unused)
     if (W > 80) return DASV_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)(p.ctiles * p.ntiles * p.S)), block(512);
+    const dim3 grid((unsigned)(DASV_WGRAD_XCD ? ((p.ctiles * p.ntiles * p.S + 7) / 8) * 8 : p.ctiles * p.ntiles * p.S)), block(512);
     const int nx = (p.xrows + 15) / 16;
 #define DASV_LAUNCH_WGRAD(SP, NXV, PT)                                                                                 \
     do {                                                                                                           \
