@@ -293,7 +293,8 @@ def main():
                                         "product, fp32 accumulate; ~5e-6 relative error vs fp32 conv)",
                                "bf16": "hand-written MFMA implicit GEMM, bf16 operands",
                                "fp16": "hand-written MFMA implicit GEMM, fp16 operands (fp32 accumulate)", "torch": "PyTorch-ROCm / MIOpen"}[args.conv]
-                              if compute_dtype == torch.float32 else "PyTorch-ROCm / MIOpen under bf16 autocast"}
+                              if compute_dtype == torch.float32 else "torch.autocast(bf16): hand-written conv kernels with bf16 operands (fp32 accumulate, "
+                              "fp32 activations), dense layers in bf16 through PyTorch-ROCm"}
         else:
             from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
             net.train()

@@ -14,7 +14,9 @@ NHWC activations; `conv_mode`:
   "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
-  "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs under autocast and for narrow layers)
+  "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs for narrow layers)
+Under `torch.autocast` the HIP kernels run with bf16 / fp16 operands (the autocast dtype), fp32 accumulation and fp32
+activations.
 conv11 (Cin = 1) and the 2x2 ceil-mode max-pools run on hand-written HIP streaming kernels too (csrc/frontend_misc.hip),
 forward and backward (arg-max recomputed; one-channel weight/bias gradient as a fixed-order reduction).
 """
@@ -64,10 +66,18 @@ class _VGG(nn.Module):
         self.fuse_first_block = False
         self._packed = {}
 
+    def _mode(self):
+        """Operand precision of the HIP convolutions for this call: `conv_mode`, except under torch.autocast, where the
+        autocast dtype picks the single-MFMA mode (bf16 / fp16 operands, fp32 accumulation and fp32 activations — at least
+        the precision autocast asks for); None = not expressible (other autocast dtypes): PyTorch-ROCm ops run."""
+        if not torch.is_autocast_enabled():
+            return self.conv_mode
+        return {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(torch.get_autocast_dtype("cuda"))
+
     def _use_hip_conv(self, name, h):
         conv = getattr(self, name)
         return (self.conv_mode != "torch" and h.is_cuda and h.dtype == torch.float32
-                and not torch.is_autocast_enabled() and conv.weight.dtype == torch.float32
+                and self._mode() is not None and conv.weight.dtype == torch.float32
                 and _hipconv.supported(conv.in_channels, conv.out_channels))
 
     def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None):
@@ -78,7 +88,7 @@ class _VGG(nn.Module):
         packed = self._packed.get(key)
         if packed is None:
             packed = self._packed[key] = _hipconv.PackedConvWeights()
-        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self.conv_mode, grad_premasked, mask_input_grad,
+        return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self._mode(), grad_premasked, mask_input_grad,
                                           link_in, link_out)
 
     def _hip_front(self, x):
@@ -86,7 +96,7 @@ class _VGG(nn.Module):
         features themselves do not need a gradient."""
         c11 = self.conv11
         return (self.conv_mode != "torch" and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
-                and not torch.is_autocast_enabled() and c11.weight.dtype == torch.float32
+                and self._mode() is not None and c11.weight.dtype == torch.float32
                 and c11.out_channels % 4 == 0 and 256 % (c11.out_channels // 4) == 0 and c11.out_channels <= 1024)
 
     def forward(self, paddedInputTensor):
@@ -104,7 +114,7 @@ class _VGG(nn.Module):
                 if packed is None:
                     packed = self._packed[key] = _hipconv.PackedConvWeights()
                 h = _hipconv.conv3x3_c1_conv3x3_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias,
-                                                          c12.weight, c12.bias, packed, self.conv_mode)
+                                                          c12.weight, c12.bias, packed, self._mode())
             elif grad:
                 h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias)
             else:
