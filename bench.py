@@ -114,6 +114,14 @@ def pmc_traffic(workload, dtype):
         return None
 
 
+def mfma_util_pmc():
+    """Matrix-pipe busy share of the conv kernels from the committed `rocprofv3 --pmc MfmaUtil` passes (profiles/)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("mfma_util_percent") or None
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -357,7 +365,8 @@ def main():
                         "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
                         "launches_per_step": len(ctimer.rec) // max(1, args.steps),
                         "mfma_flops_executed_per_algorithmic_flop": mult,
-                        "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4)}
+                        "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
+                        "mfma_util_pmc_percent": mfma_util_pmc()}
         # reduced-precision companion (never the headline `value`): same step with fp16 conv operands (fp32 accumulate,
         # fp32 activations), with its measured embedding error against the fp32-grade path on the same batch
         reduced = None

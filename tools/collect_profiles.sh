@@ -14,6 +14,9 @@ echo "== pmc FETCH_SIZE: pool" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --ou
 echo "== pmc WRITE_SIZE: pool" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pool_write -- $POOL > $OUT/pool_write.log 2>&1 || tail -5 $OUT/pool_write.log
 echo "== pmc FETCH_SIZE: embed" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/embed_fetch -- $EMBED > $OUT/embed_fetch.log 2>&1 || tail -5 $OUT/embed_fetch.log
 echo "== pmc WRITE_SIZE: embed" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/embed_write -- $EMBED > $OUT/embed_write.log 2>&1 || tail -5 $OUT/embed_write.log
+TRAIN="python3 bench.py --workload train --steps 3 --warmup 2 --no-cpu-baseline"
+echo "== pmc MfmaUtil: embed" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/embed_mfma -- $EMBED > $OUT/embed_mfma.log 2>&1 || tail -5 $OUT/embed_mfma.log
+echo "== pmc MfmaUtil: train" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/train_mfma -- $TRAIN > $OUT/train_mfma.log 2>&1 || tail -5 $OUT/train_mfma.log
 # keep only what the summary needs (the kernel_trace of the embed run is large)
 find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT

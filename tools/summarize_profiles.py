@@ -118,6 +118,24 @@ for run in ("pool", "embed"):
         pr = bl.get("roofline_pooling") or bl["roofline"]
         md.append("* bench.py under the profiler: value %.1f %s; pooling-kernel avg_launch_us %.2f by events (includes the event/launch gap)\n"
                   % (bl["value"], bl["unit"], pr["avg_launch_us"]))
+# MFMA utilisation from the PMC passes (derived counter MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs))
+util = {}
+for run in ("embed", "train"):
+    path = one("%s_mfma/*/*counter_collection.csv" % run)
+    if not path:
+        continue
+    agg = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == "MfmaUtil" and ("conv3x3_window_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"]):
+            agg.setdefault(r["Kernel_Name"].replace("void ", "")[:70], []).append(float(r["Counter_Value"]))
+    if agg:
+        md.append("\n## MFMA utilisation (`rocprofv3 --pmc MfmaUtil --kernel-trace`, `%s` workload)\n\n" % run)
+        md.append("MfmaUtil = matrix-core busy cycles / (GPU active cycles x SIMDs), per dispatch, in percent of the matrix pipe's "
+                  "time (the pipe's peak is the 2.5 PFLOP/s dense bf16 figure).\n\n| kernel | dispatches | mean | max |\n|---|---|---|---|\n")
+        for k, v in sorted(agg.items()):
+            md.append("| `%s` | %d | %.1f %% | %.1f %% |\n" % (k, len(v), sum(v) / len(v), max(v)))
+            util["%s:%s" % (run, k)] = round(sum(v) / len(v), 2)
+traffic["mfma_util_percent"] = util
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("".join(md))
 print("".join(md))
