@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             // Measured alternatives that did NOT help: pinning these loads here with a sched_barrier (the scheduler sinks
             // them to the end of the MFMA section): no change; a two-deep software pipeline (tile of tap+2 fetched at the
             // top, tile of tap+1 written to the other buffer between the two MFMA halves, so no store sits between a
-            // barrier and the first fragment reads): 4.5 % slower at 255 registers.
+            // barrier and the first fragment reads): 4.5 % slower at 255 registers; fetching the NEXT tap's first-half pixel
+            // fragments before the barrier (the window is unchanged within a slab): 2.5 % slower at 251 registers.
             const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
             for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {
