@@ -292,8 +292,13 @@ constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 51
 
 // C1: the input activations are produced on the fly by a one-input-channel conv3x3+bias+ReLU over `mel` (conv11 fused
 // into conv12: its 786 MB output never exists in HBM).
-template <int PREC, bool DBUF, bool C1>
-__global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p) {
+template <int PREC, bool DBUF, bool C1, int NWN>
+__global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvParams p) {
+    // NWN waves along the 128 output channels (x 4 along the 256 pixels): 2 -> 8 waves of 64 x 64 outputs, 4 -> 16 waves of
+    // 64 x 32 (more waves per SIMD to overlap each other's barrier / fragment-read waits, at more LDS reads per MFMA)
+    static_assert(NWN == 2 || NWN == 4, "wave layout");
+    static_assert(!C1 || NWN == 2, "the fused first layer stages with the 512-thread layout");
+    constexpr int NT = 256 * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = (WMAXROWS * 16 + NT - 1) / NT, BCH = 1024 / NT;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int m0 = mt * WBM, n0 = nt * CBN;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv / NWN, wn = wv % NWN;
     const int frow = lane & 15, fq = lane >> 4;
 
     // border masks of this lane's four A-fragment pixels
@@ -337,14 +342,14 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
         amask[i] = mask;
     }
 
-    // A window staging: chunk q = tid + 512*k covers window row q/16, fp32 chunk q%16 (4 channels)
+    // A window staging: chunk q = tid + NT*k covers window row q/16, fp32 chunk q%16 (4 channels)
     const int wchunks = wrows * 16;
     const long long wbase = (long long)m0 - W - 1;   // global pixel index of window row 0
-    f32x4 ra[WACH];
+    f32x4 ra[WACHN];
     auto load_window = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < WACH; ++k) {
-            const int q = tid + 512 * k;
+        for (int k = 0; k < WACHN; ++k) {
+            const int q = tid + NT * k;
             const long long pix = wbase + (q >> 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < wchunks && pix >= 0 && pix < p.M) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * Cin + c0 + (q & 15) * 4);
@@ -353,8 +358,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     };
     auto store_window = [&]() {
 #pragma unroll
-        for (int k = 0; k < WACH; ++k) {
-            const int q = tid + 512 * k;
+        for (int k = 0; k < WACHN; ++k) {
+            const int q = tid + NT * k;
             if (q < wchunks) {
                 const int row = q >> 4, ach = q & 15;
                 uint32_t h0, l0, h1, l1;
@@ -418,12 +423,12 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
             }
         }
     };
-    // B staging: 128 rows x 8 chunks per plane = 1024 chunks; thread handles chunk tid and tid + 512
-    u32x4 rbh[2], rbl[2];
+    // B staging: 128 rows x 8 chunks per plane = 1024 chunks; BCH chunks per thread
+    u32x4 rbh[BCH], rbl[BCH];
     auto load_b = [&](int tap, int c0) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = tid + 512 * k;
+        for (int k = 0; k < BCH; ++k) {
+            const int q = tid + NT * k;
             const size_t off = ((size_t)(n0 + (q >> 3)) * 9 + tap) * Cin + c0 + (q & 7) * 8;
             rbh[k] = *reinterpret_cast<const u32x4*>(p.whi + off);
             if (SPLIT) rbl[k] = *reinterpret_cast<const u32x4*>(p.wlo + off);
@@ -431,19 +436,19 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     };
     auto store_b = [&](char* Bhi) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = tid + 512 * k;
+        for (int k = 0; k < BCH; ++k) {
+            const int q = tid + NT * k;
             const int o = lds_off(q >> 3, q & 7);
             *reinterpret_cast<u32x4*>(Bhi + o) = rbh[k];
             if (SPLIT) *reinterpret_cast<u32x4*>(Bhi + 16384 + o) = rbl[k];
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][JT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // split-K: this workgroup covers channel slabs [sl_lo, nslab) of the Cin / 64
     const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
@@ -473,10 +478,10 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
 #pragma unroll
             for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {
                 const int slot = kk * 4 + fq;
-                bf16x8 bh[4], bl[4];
+                bf16x8 bh[JT], bl[JT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int o = lds_off(wn * 64 + j * 16 + frow, slot);
+                for (int j = 0; j < JT; ++j) {
+                    const int o = lds_off(wn * NPW + j * 16 + frow, slot);
                     bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + o);
                     if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Bhi + 16384 + o);
                 }
@@ -493,7 +498,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
                     ah = ok ? ah : zero;
                     if (SPLIT) al = ok ? al : zero;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < JT; ++j) {
                         // weights as the A operand, pixels as B: the 16x16 result has channels on its rows, so a
                         // lane ends up with 4 consecutive channels of one pixel (16-byte stores in the epilogue)
                         acc[i][j] = mma16<PREC>(bh[j], ah, acc[i][j]);
@@ -511,8 +516,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     if (p.ksplit > 1) {   // raw partial sums; conv3x3_splitk_reduce adds them up and applies bias / ReLU / mask
         float* part = p.part + (size_t)ks * p.M * p.Cout;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < JT; ++j) {
+            const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -525,8 +530,8 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
     float* red = reinterpret_cast<float*>(smem);   // [4 wm][128 channels] partial column sums (colsum only)
     if (p.colsum != nullptr) __syncthreads();      // every wave is done with the LDS tiles
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < JT; ++j) {
+        const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__(512) conv3x3_window_kernel(const ConvParams p)
         if (p.colsum != nullptr) {   // fixed-order reduction: 4 pixel blocks (above), 16 lanes (DPP), then the 4 pixel waves
 #pragma unroll
             for (int r = 0; r < 4; ++r) csum[r] = group_sum<16>(csum[r]);
-            if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(red + wm * 128 + wn * 64 + j * 16 + (lane >> 4) * 4) = csum;
+            if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(red + wm * 128 + wn * NPW + j * 16 + (lane >> 4) * 4) = csum;
         }
     }
     if (p.colsum != nullptr) {
@@ -661,22 +666,25 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             p.ksplit = S;
         }
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8 * p.ksplit)), block(512);
-#define DASV_LAUNCH_WINDOW(SP, DB, CC)                                                                               \
+#define DASV_LAUNCH_WINDOW(SP, DB, CC, NW)                                                                           \
         do {                                                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC>), \
+            constexpr int nwn_ = NW;                                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC, nwn_>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (e != hipSuccess) return (int)e;                                                                      \
-            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC>), grid, block, lds, s, p);                    \
+            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC, nwn_>), grid, dim3(256 * nwn_), lds, s, p);    \
         } while (0)
+        // wave layout: 8 waves (64 x 64 outputs each) everywhere except the single-buffered split launches (80-column maps:
+        // two barriers per tap), where 16 waves of 64 x 32 hide each other's waits: conv12 1.32 -> 1.20 ms (interleaved A/B)
         if (p.mel != nullptr) {
-            if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, true);
-            else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true);
-            else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true);
-            else DASV_LAUNCH_WINDOW(2, false, true);
-        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false);
-        else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false);
-        else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false);
-        else DASV_LAUNCH_WINDOW(2, false, false);
+            if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, true, 2);
+            else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true, 2);
+            else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true, 2);
+            else DASV_LAUNCH_WINDOW(2, false, true, 2);
+        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false, 2);
+        else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false, 4);
+        else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false, 2);
+        else DASV_LAUNCH_WINDOW(2, false, false, 2);
 #undef DASV_LAUNCH_WINDOW
         if (p.ksplit > 1) {
             hipError_t e = hipGetLastError();
