@@ -1,3 +1,4 @@
+"""Diagnostic: every HIP conv layer's weight/bias gradient inside a full VGG4L backward vs ATen on the same saved tensors."""
 import sys, os, copy, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from doubleattentionspeakerverification_amd.CNNs import VGG4L

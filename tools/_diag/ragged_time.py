@@ -1,3 +1,4 @@
+"""Diagnostic: where the time of the ragged embedding path goes (border tables, front-end, pooling) vs a dense batch."""
 import sys, os, time, argparse, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from doubleattentionspeakerverification_amd.model import SpeakerClassifier

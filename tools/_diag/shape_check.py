@@ -1,3 +1,4 @@
+"""Diagnostic: forward / weight-gradient / data-gradient accuracy of the conv kernels vs float64 on small-batch shapes."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from doubleattentionspeakerverification_amd import conv as C

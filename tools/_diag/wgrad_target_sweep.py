@@ -1,3 +1,4 @@
+"""Diagnostic: weight-gradient time vs the number of workgroups the pixel range is split for (DASV_WGRAD_TARGET), interleaved."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from doubleattentionspeakerverification_amd import conv
