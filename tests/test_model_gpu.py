@@ -529,6 +529,15 @@ def test_masked_conv_and_relu_pool_backward_entry_points():
     assert rc == 0 and rows > 0
     assert torch.equal(gx, pre.grad)
     np.testing.assert_allclose(part.sum(0).cpu().numpy(), pre.grad.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # the same on an 80-column map (single-buffered 16-wave launch): masked values and their column sums
+    g80 = torch.from_numpy(rnd(76, 1, 128, 7, 80)).to(DEV).contiguous(memory_format=torch.channels_last)
+    x80 = torch.relu(torch.from_numpy(rnd(77, 1, 128, 7, 80))).to(DEV).contiguous(memory_format=torch.channels_last)
+    l80 = {}
+    got80 = conv._launch(g80, hi, lo, None, 128, "split", relu=0, mask=x80, colsum=l80)
+    ref80 = torch.nn.functional.conv2d(g80.double().cpu(), wt.double().cpu(), None, padding=1) * (x80.cpu() > 0)
+    assert float((got80.cpu().double() - ref80).abs().max()) <= 2e-5 * float(ref80.abs().max())
+    np.testing.assert_allclose(l80["gb"].cpu().numpy(), got80.sum(dim=(0, 2, 3)).cpu().numpy(), rtol=1e-5,
+                               atol=1e-5 * float(got80.sum(dim=(0, 2, 3)).abs().max()))
     # column sums of the masked data gradient (the bias gradient of the layer below)
     link = {}
     got2 = conv._launch(g, hi, lo, None, 128, "split", relu=0, mask=xin, colsum=link)
