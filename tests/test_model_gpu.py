@@ -648,3 +648,31 @@ def test_ragged_batch_equals_one_utterance_per_forward():
             r2 = torch.cat([net2.getEmbedding(u.unsqueeze(0)) for u in utts[:4]])
         e2 = embed_ragged(net2, utts[:4])
         assert float((e2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), method
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 at its full size (default model, [64,300,80]), checked through properties that need no CPU run of
+    39 GFLOP per utterance: (1) utterances are independent of their batch-mates — rows of the batched embedding equal the
+    one-utterance embeddings (the reference's own scoring path is B=1, train.py:117-133); (2) duplicated utterances give
+    identical rows; (3) the front-end commutes with a shift in time away from the borders (conv/pool stack with total
+    stride 16: a 16-frame shift of the input moves the frame embeddings by one row)."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=5994, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).eval()
+    x = torch.from_numpy(rnd(123, 64, 300, 80)).to(DEV)
+    x[17] = x[3]
+    with torch.no_grad():
+        emb = net.getEmbedding(x)
+        assert emb.shape == (64, 400) and torch.isfinite(emb).all()
+        assert torch.equal(emb[17], emb[3])                                            # (2)
+        for i in (0, 3, 40, 63):                                                       # (1)
+            one = net.getEmbedding(x[i:i + 1])
+            assert float((one[0] - emb[i]).abs().max()) <= 2e-5 * float(emb.abs().max()), i
+        frames = net.front_end(x[:4])                                                  # [4, 19, 5120]
+        shifted = net.front_end(torch.roll(x[:4], shifts=16, dims=1))
+        # rows 3..17 of the shifted map see exactly the samples rows 2..16 saw (receptive field of a row is ~+-46 input frames;
+        # keep a margin from both ends where the wrap-around / zero padding differs)
+        a, b = shifted[:, 5:15], frames[:, 4:14]
+        assert float((a - b).abs().max()) <= 2e-5 * float(frames.abs().max())
