@@ -473,7 +473,9 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             // them to the end of the MFMA section): no change; a two-deep software pipeline (tile of tap+2 fetched at the
             // top, tile of tap+1 written to the other buffer between the two MFMA halves, so no store sits between a
             // barrier and the first fragment reads): 4.5 % slower at 255 registers; fetching the NEXT tap's first-half pixel
-            // fragments before the barrier (the window is unchanged within a slab): 2.5 % slower at 251 registers.
+            // fragments before the barrier (the window is unchanged within a slab): 2.5 % slower at 251 registers; 128-pixel
+            // tiles with a single weight buffer (<= 80 KB of LDS on maps up to 20 columns, so two workgroups share a CU and
+            // desynchronise): 4-7 % slower on those layers (128 registers with spills, more halo and fragment reads per MFMA).
             const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
             for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {
