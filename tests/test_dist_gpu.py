@@ -1,0 +1,59 @@
+"""The RCCL code path of the data-parallel trainer on the one GPU a test box has: a 1-rank `nccl` process group
+(backend "nccl" IS RCCL on ROCm) with the reducer told there are two ranks, so every gradient bucket really goes through an
+asynchronous RCCL all-reduce launched from the autograd hooks during backward, is waited on and averaged.  With one real
+rank the sum is the identity, so the step must equal a plain step with half the gradient."""
+import argparse
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
+    import torch.distributed as dist
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                               embedding_size=400, num_spkrs=64, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+        torch.manual_seed(4)
+        net = SpeakerClassifier(p, dev).to(dev).train()
+        ref = copy.deepcopy(net)
+        rs = np.random.RandomState(8)
+        x = torch.from_numpy(rs.standard_normal((4, 61, 80)).astype(np.float32)).to(dev)
+        y = torch.tensor([3, 9, 9, 60], device=dev)
+        trainer = DataParallelTrainer(net, lr=0.05, weight_decay=0.0, optimizer="SGD", bucket_bytes=8 << 20)
+        assert len(trainer.reducer.buckets) >= 4
+        trainer.reducer.world = 2                    # pretend: forces the collective path; the 1-rank sum is the identity
+        launched = []
+        orig = trainer.reducer._launch
+
+        def spy(bi):
+            launched.append(bi)
+            return orig(bi)
+        trainer.reducer._launch = spy
+        torch.manual_seed(99)                        # same train-time head mask in both runs
+        loss, _ = trainer.train_step(x, y, step=0)
+        assert sorted(set(launched)) == list(range(len(trainer.reducer.buckets)))
+        # plain step with lr/2 on the copy == averaging the "two ranks'" identical gradients
+        opt = torch.optim.SGD(ref.parameters(), lr=0.025, weight_decay=0.0)
+        torch.manual_seed(99)
+        _, logits = ref(x, label=y, step=0)
+        l2 = torch.nn.functional.cross_entropy(logits, y)
+        l2.backward()
+        opt.step()
+        assert abs(float(loss) - float(l2.detach())) < 1e-5
+        for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+            assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
+    finally:
+        if created:
+            dist.destroy_process_group()
