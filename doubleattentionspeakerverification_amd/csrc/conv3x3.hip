@@ -510,6 +510,14 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                         }
                     }
                 }
+                // scheduling hint for this 32-channel half in the 8-wave layouts: all sixteen fragment reads first, then the
+                // selects and the MFMAs — 1-3 % on the double-buffered layers (interleaved A/B); a {12 MFMAs, next block's reads}
+                // pipeline was 2 % slower, and in the 16-wave layout either hint costs 5-7 %
+                if constexpr (NWN == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);
+                }
             }
             if (!DBUF) __syncthreads();
         }
