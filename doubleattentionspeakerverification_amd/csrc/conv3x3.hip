@@ -35,6 +35,9 @@ constexpr int CBM = 128, CBN = 128, CBK = 64;
 #ifndef DASV_CONV_DIAG
 #define DASV_CONV_DIAG 0
 #endif
+#ifndef DASV_CONV_SCHED
+#define DASV_CONV_SCHED 1   // reads-first scheduling hint (tools/conv_diag.py A/B)
+#endif
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -511,9 +514,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     }
                 }
                 // scheduling hint for this 32-channel half in the 8-wave layouts: all sixteen fragment reads first, then the
-                // selects and the MFMAs — 1-3 % on the double-buffered layers (interleaved A/B); a {12 MFMAs, next block's reads}
-                // pipeline was 2 % slower, and in the 16-wave layout either hint costs 5-7 %
-                if constexpr (NWN == 2) {
+                // selects and the MFMAs — 0-3 % on the double-buffered split layers (interleaved A/B, two runs); a {12 MFMAs, next
+                // block's reads} pipeline was 2 % slower, in the 16-wave layout either hint costs 5-7 %, and in the single-MFMA
+                // modes this one costs 5 %
+                if constexpr (SPLIT && NWN == 2 && DASV_CONV_SCHED != 0) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);

@@ -6,7 +6,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIAG = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "doubleattentionspeakerverification_amd", "csrc", "conv3x3.hip")
-NAMES = {0: "full", 1: "window staged once", 2: "no MFMA", 3: "weights staged once"}
+NAMES = {0: "full", 1: "window staged once", 2: "no MFMA", 10: "full, no scheduling hint"}
 
 
 def so(n):
@@ -17,7 +17,7 @@ def build():
     os.makedirs(DIAG, exist_ok=True)
     for n in NAMES:
         subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                               "-DDASV_CONV_DIAG=%d" % n, SRC, "-o", so(n)])
+                               "-DDASV_CONV_DIAG=%d" % (n % 10), "-DDASV_CONV_SCHED=%d" % (1 - n // 10), SRC, "-o", so(n)])
 
 
 def time_round_robin(gos, rounds=3, reps=4):
