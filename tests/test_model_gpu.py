@@ -676,3 +676,39 @@ def test_config3_full_size_properties():
         # keep a margin from both ends where the wrap-around / zero padding differs)
         a, b = shifted[:, 5:15], frames[:, 4:14]
         assert float((a - b).abs().max()) <= 2e-5 * float(frames.abs().max())
+
+
+def test_training_trajectory_hip_path_tracks_pytorch_path():
+    """Three SGD steps of the default architecture on a fixed tiny batch: the losses of the all-HIP training path (conv
+    forward / data gradient / weight gradient, pools, conv11, fused masks and bias sums, pooling forward/backward) must
+    track the PyTorch-ROCm path — a wrong gradient anywhere shows up in the loss right after the first update.  (SGD, not
+    Adam: Adam's first steps move every parameter by +-lr whatever the gradient's size, so noise-level gradients turn
+    rounding differences into full-size update differences.  Only three steps: with a batch of four through train-mode
+    BatchNorm and a x30 logit scale the dynamics amplify any 1e-6 difference ~50x per step in BOTH implementations.)"""
+    import copy
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=16, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(31)
+    net_a = SpeakerClassifier(p, torch.device(DEV)).to(DEV).train()
+    net_b = copy.deepcopy(net_a)
+    net_b.front_end.conv_mode = "torch"
+    x = torch.from_numpy(rnd(131, 4, 61, 80)).to(DEV)
+    y = torch.tensor([1, 5, 5, 12], device=DEV)
+    losses = {}
+    for tag, net in (("hip", net_a), ("torch", net_b)):
+        opt = torch.optim.SGD(net.parameters(), lr=0.002)
+        cur = []
+        for step in range(3):
+            torch.manual_seed(1000 + step)            # same train-time head mask in both runs
+            opt.zero_grad(set_to_none=True)
+            _, logits = net(x, label=y, step=step)
+            loss = torch.nn.functional.cross_entropy(logits, y)
+            loss.backward()
+            opt.step()
+            cur.append(float(loss.detach()))
+        losses[tag] = cur
+    print("loss curves:", [round(v, 4) for v in losses["hip"]], [round(v, 4) for v in losses["torch"]])
+    assert abs(losses["hip"][1] - losses["hip"][0]) > 0.5              # the update really changed the loss
+    for (a, b), tol in zip(zip(losses["hip"], losses["torch"]), (1e-5, 2e-4, 4e-3)):
+        assert abs(a - b) <= tol * abs(b), (losses["hip"], losses["torch"])
