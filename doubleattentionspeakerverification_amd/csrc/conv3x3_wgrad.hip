@@ -172,12 +172,28 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
         }
         const unsigned g_thread_patch = (unsigned)(n0 + scc * 4) * 4u + (unsigned)((srow >> 3) * W + (srow & 7)) * g_rowbytes;
         const int patches_per_row = W >> 3;
-        auto fetch = [&](int ch) {
+        // Chunks are fetched in order, so the chunk -> (utterance, row, column) decode is carried from one fetch to the next
+        // (wave-uniform scalar adds) instead of being divided out again each time.
+        int cb = chunk_lo / p.chunks_per_image;                 // utterance of the next chunk to fetch
+        int cpi = chunk_lo - cb * p.chunks_per_image;           // its index inside the utterance
+        int ch0 = PATCH ? (cpi / patches_per_row) * 8 : (cpi * WKC) / W;                     // first row
+        int cw0 = PATCH ? (cpi - (cpi / patches_per_row) * patches_per_row) * 8 : cpi * WKC - ((cpi * WKC) / W) * W;   // first column
+        const int dh64 = WKC / W, dw64 = WKC - dh64 * W;        // raster: 64 pixels = dh64 rows + dw64 columns
+        auto advance = [&]() {
+            if (++cpi == p.chunks_per_image) { cpi = 0; ++cb; ch0 = 0; cw0 = 0; return; }
             if constexpr (PATCH) {
-                const int b = ch / p.chunks_per_image;
-                const int pi = ch - b * p.chunks_per_image;
-                const int py = pi / patches_per_row;               // wave-uniform: once per chunk
-                const int h0 = py * 8, w0 = (pi - py * patches_per_row) * 8;
+                cw0 += 8;
+                if (cw0 >= W) { cw0 = 0; ch0 += 8; }
+            } else {
+                cw0 += dw64;
+                ch0 += dh64;
+                if (cw0 >= W) { cw0 -= W; ++ch0; }
+            }
+        };
+        auto fetch = [&](int) {
+            if constexpr (PATCH) {
+                const int b = cb, h0 = ch0, w0 = cw0;
+                advance();
                 const unsigned gbase = (unsigned)((b * H + h0) * W + w0) * g_rowbytes + g_thread_patch;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -193,10 +209,9 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
                 }
                 return;
             }
-            const int b = ch / p.chunks_per_image;
-            const int off = (ch - b * p.chunks_per_image) * WKC;
+            const int b = cb, off = cpi * WKC, h0 = ch0, w0 = cw0;
             const int npx = min(WKC, HW - off);
-            const int h0 = off / W, w0 = off - h0 * W;    // wave-uniform: once per chunk
+            advance();
             w0_next = w0;
             const unsigned gbase = (unsigned)(b * HW + off) * g_rowbytes + g_thread;
 #pragma unroll
