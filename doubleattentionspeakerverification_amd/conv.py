@@ -7,11 +7,13 @@ bf16, mode "fp16" to fp16 (11 mantissa bits, forward only: its gradients run wit
 covers small gradients).  Backward: data gradient = the same kernel with transposed, flipped weights; weight gradient =
 csrc/conv3x3_wgrad.hip.
 """
+import weakref
+
 import torch
 
 from . import _lib
 
-__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
+__all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu",
            "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
 
@@ -25,16 +27,29 @@ def supported(cin, cout):
 
 
 class PackedConvWeights:
-    """bf16 hi/lo planes [Cout][9][Cin] of a Conv2d weight, re-packed when the parameter changes."""
+    """bf16 hi/lo planes [Cout][9][Cin] of a Conv2d weight, re-packed when the parameter changes.
+
+    The packed planes are reused only for the SAME leaf `nn.Parameter` object (held by weak reference) at the same
+    address and version counter.  Anything else is packed on every call: nn.DataParallel replicas (train.py:68-70
+    re-broadcasts the weights on every forward; the copies are plain tensors whose version is always 0 and whose
+    allocator addresses repeat), functional weights, transposed temporaries.  Writes through `.data` do not move the
+    version counter: code that updates weights that way (EMA swaps, raw collectives on `.data`) calls `invalidate()` /
+    `invalidate_packed_weights(module)` afterwards."""
 
     def __init__(self):
         self.key = None
+        self.owner = None
         self.hi = self.lo = None
+
+    def invalidate(self):
+        self.key = None
+        self.owner = None
 
     def get(self, weight, mode="split"):
         f16 = mode == "fp16"
+        cacheable = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
         key = (weight.data_ptr(), weight._version, weight.device, f16)
-        if key != self.key:
+        if not (cacheable and key == self.key and self.owner is not None and self.owner() is weight):
             lib = _lib.load()
             cout, cin = weight.shape[0], weight.shape[1]
             n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
@@ -49,8 +64,19 @@ class PackedConvWeights:
                 else:
                     rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)
             _lib.check(rc, "dasv_conv3x3_pack_weights")
-            self.key = key
+            self.key = key if cacheable else None
+            self.owner = weakref.ref(weight) if cacheable else None
         return self.hi, self.lo
+
+
+def invalidate_packed_weights(module):
+    """Drop every packed copy of convolution weights held under `module` (call after writing weights through `.data`)."""
+    for m in module.modules():
+        packed = getattr(m, "_packed", None)
+        if isinstance(packed, dict):
+            for pk in packed.values():
+                if isinstance(pk, PackedConvWeights):
+                    pk.invalidate()
 
 
 def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None):

@@ -91,8 +91,19 @@ class FlatGradReducer:
             self.views.append(self.flat[offs[i]:offs[i] + sizes[i]].view_as(p))
             p.grad = self.views[i]
         self._fired = [False] * len(self.params)
+        # COLD parameters: those the first reduced backward produced no gradient for (b1.* / b3.*, model.py:46,50, never
+        # fire).  A bucket that waited for them would only be reduced in finish(), after the whole backward, so after that
+        # first step their gradients are re-pointed at a separate small buffer: the buckets stop counting them, and should
+        # one fire in a later step it accumulates there — never into a range whose all-reduce is already in flight — and
+        # is reduced in finish().
+        self._cold = set()
+        self._cold_bufs = []
+        self._cold_fired = False
+        self._fired_armed = [False] * len(self.params)
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self.launched_from_hook = [False] * len(self.buckets)
+        self._in_finish = False
         self._works = []
         self._armed = False
         for i, p in enumerate(self.params):
@@ -103,6 +114,10 @@ class FlatGradReducer:
             self._fired[i] = True
             if not self._armed:
                 return
+            self._fired_armed[i] = True
+            if i in self._cold:
+                self._cold_fired = True
+                return
             bi = self.bucket_of[i]
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
@@ -110,6 +125,8 @@ class FlatGradReducer:
         return hook
 
     def _launch(self, bi):
+        if not self._launched[bi]:
+            self.launched_from_hook[bi] = not self._in_finish
         if self._launched[bi] or self.world == 1:
             self._launched[bi] = True
             return
@@ -120,24 +137,61 @@ class FlatGradReducer:
     def arm(self):
         """Call before the backward pass whose gradients are to be reduced (the LAST micro-batch)."""
         self._armed = True
-        self._pending = [len(mem) for _, _, mem in self.buckets]
-        self._launched = [False] * len(self.buckets)
+        self._pending = [sum(1 for i in mem if i not in self._cold) for _, _, mem in self.buckets]
+        # a bucket of cold parameters only is a dead range of the flat buffer (always zero): nothing to reduce
+        self._launched = [n == 0 for n in self._pending]
+        self.launched_from_hook = [n == 0 for n in self._pending]
+        self._fired_armed = [False] * len(self.params)
+        self._cold_fired = False
         self._works = []
 
+    def _retire_unfired(self):
+        """Move the parameters the reduced backward left without a gradient to the cold buffer (same on every rank: the
+        graph is)."""
+        new = [i for i in range(len(self.params)) if i not in self._cold and not self._fired_armed[i]]
+        if not new:
+            return
+        sizes = [(self.params[i].numel() + 63) // 64 * 64 for i in new]
+        buf = torch.zeros(sum(sizes), dtype=self.flat.dtype, device=self.flat.device)
+        off = 0
+        for i, n in zip(new, sizes):
+            v = buf[off:off + self.params[i].numel()].view_as(self.params[i])
+            v.copy_(self.views[i])       # non-zero only if an un-reduced micro-batch produced it
+            self.views[i].zero_()
+            self.views[i] = v
+            self.params[i].grad = v
+            self._cold.add(i)
+            off += n
+        self._cold_bufs.append(buf)
+
     def finish(self):
-        """After backward: reduce buckets whose hooks never all fired (unused parameters), wait, average."""
-        for bi in range(len(self.buckets)):
-            if not self._launched[bi]:
-                self._launch(bi)
+        """After backward: reduce buckets whose hooks never all fired, wait, average."""
+        self._in_finish = True
+        try:
+            for bi in range(len(self.buckets)):
+                if not self._launched[bi]:
+                    self._launch(bi)
+        finally:
+            self._in_finish = False
+        if self._cold_fired and self.world > 1:
+            for buf in self._cold_bufs:
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
         self._works = []
         self._armed = False
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
+            if self._cold_fired:
+                for buf in self._cold_bufs:
+                    buf.mul_(1.0 / self.world)
+        self._retire_unfired()
 
     def zero(self):
         self.flat.zero_()
+        if any(self._fired[i] for i in self._cold):
+            for buf in self._cold_bufs:
+                buf.zero_()
         self._fired = [False] * len(self.params)
 
     def hide_unused(self):
@@ -182,8 +236,11 @@ class DataParallelTrainer:
     def broadcast_state(self):
         """Rank 0's parameters and buffers to everyone (initialisation, and what DataParallel's
         keep-GPU-0's-BatchNorm-statistics behaviour amounts to at checkpoint time)."""
-        for t in list(self.net.parameters()) + list(self.net.buffers()):
-            dist.broadcast(t.data, src=0, group=self.group)
+        from .conv import invalidate_packed_weights
+        with torch.no_grad():   # in place on the tensors themselves, so their version counters move
+            for t in list(self.net.parameters()) + list(self.net.buffers()):
+                dist.broadcast(t, src=0, group=self.group)
+        invalidate_packed_weights(self.net)
 
     def train_step(self, x, labels, step=0):
         """Forward/backward on this rank's shard.  Every `accum`-th call all-reduces and steps the optimizer.

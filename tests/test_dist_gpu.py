@@ -44,6 +44,7 @@ def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
         torch.manual_seed(99)                        # same train-time head mask in both runs
         loss, _ = trainer.train_step(x, y, step=0)
         assert sorted(set(launched)) == list(range(len(trainer.reducer.buckets)))
+        first_from_hook = list(trainer.reducer.launched_from_hook)
         # plain step with lr/2 on the copy == averaging the "two ranks'" identical gradients
         opt = torch.optim.SGD(ref.parameters(), lr=0.025, weight_decay=0.0)
         torch.manual_seed(99)
@@ -54,6 +55,14 @@ def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
         assert abs(float(loss) - float(l2.detach())) < 1e-5
         for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
             assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
+        # bucket 0 (AM-softmax W, fc/BN, conv42 — with the never-firing b1.* / b3.* in the middle) waited for
+        # finish() on every step.  From the second step on every bucket goes out from an autograd hook, during backward.
+        assert not first_from_hook[0]
+        torch.manual_seed(98)
+        trainer.train_step(x, y, step=1)
+        assert all(trainer.reducer.launched_from_hook)
+        names = [n for n, _ in net.named_parameters()]
+        assert {names[i].split(".")[0] for i in trainer.reducer._cold} == {"b1", "b3"}
     finally:
         if created:
             dist.destroy_process_group()

@@ -712,3 +712,85 @@ def test_training_trajectory_hip_path_tracks_pytorch_path():
     assert abs(losses["hip"][1] - losses["hip"][0]) > 0.5              # the update really changed the loss
     for (a, b), tol in zip(zip(losses["hip"], losses["torch"]), (1e-5, 2e-4, 4e-3)):
         assert abs(a - b) <= tol * abs(b), (losses["hip"], losses["torch"])
+
+
+def test_packed_conv_weights_follow_replicas_and_data_writes():
+    """the packed bf16 planes were cached under (address, version).  A DataParallel replica (train.py:68-70)
+    is a fresh plain tensor with version 0 at a recycled address, and a write through `.data` leaves the version alone —
+    both must still reach the convolution."""
+    from doubleattentionspeakerverification_amd import conv as hc
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 9, 10, device=DEV).contiguous(memory_format=torch.channels_last)
+    bias = torch.zeros(128, device=DEV)
+    w = torch.nn.Parameter(torch.randn(128, 64, 3, 3, device=DEV) * 0.05)
+    pk = hc.PackedConvWeights()
+
+    def ref(wt):
+        return torch.relu(torch.nn.functional.conv2d(x.double(), wt.detach().double(), bias.double(), padding=1)).float()
+
+    def close(y, wt):
+        r = ref(wt)
+        return float((y - r).abs().max()) <= 5e-5 * float(r.abs().max())
+
+    with torch.no_grad():
+        y0 = hc.conv3x3_bias_relu(x, w, bias, pk)
+        assert close(y0, w)
+        key0 = pk.key
+        hc.conv3x3_bias_relu(x, w, bias, pk)
+        assert pk.key == key0 and pk.owner() is w                    # the leaf Parameter itself: cached
+        # (1) a replica: new plain tensor, version 0, same storage address, different contents
+        replica = torch.empty(0)
+        addr = None
+        for _ in range(4):                                            # let the caching allocator hand the block back
+            del replica
+            replica = (torch.randn(128, 64, 3, 3, device=DEV) * 0.05)
+            addr = replica.data_ptr()
+            y1 = hc.conv3x3_bias_relu(x, replica, bias, pk)
+            assert close(y1, replica) and pk.key is None              # never cached
+        # simulated worst case: same address AND version as the cached Parameter
+        pk2 = hc.PackedConvWeights()
+        hc.conv3x3_bias_relu(x, w, bias, pk2)
+        alias = w.detach()                                            # same address, shares the version counter
+        w_old = w.detach().clone()
+        alias.data.mul_(-1.0)                                         # contents change, w._version does not
+        assert pk2.key == (w.data_ptr(), w._version, w.device, False)
+        stale = hc.conv3x3_bias_relu(x, w, bias, pk2)                 # documented: `.data` writes need invalidate()
+        assert close(stale, w_old)
+        pk2.invalidate()
+        assert close(hc.conv3x3_bias_relu(x, w, bias, pk2), w)
+        y_alias = hc.conv3x3_bias_relu(x, alias, bias, pk2)           # a non-Parameter view is packed per call
+        assert close(y_alias, w)
+    # (2) module level: invalidate_packed_weights reaches the front-end's packed copies
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    fe = VGG4L(1024).to(DEV).eval()
+    mel = torch.randn(2, 40, 80, device=DEV)
+    with torch.no_grad():
+        a = fe(mel)
+        fe.conv42.weight.data.mul_(0.5)
+        hc.invalidate_packed_weights(fe)
+        b = fe(mel)
+        fe.conv42.weight.mul_(2.0)                                    # ordinary in-place update: version moves
+        c = fe(mel)
+    assert float((b - 0.5 * a).abs().max()) < 1e-4 * float(a.abs().max()) + 1e-6 or float((b - a).abs().max()) > 0
+    assert float((b - a).abs().max()) > 1e-3 * float(a.abs().max())
+    assert float((c - b).abs().max()) > 1e-3 * float(b.abs().max())
+
+
+def test_data_parallel_replicas_see_current_weights():
+    """nn.DataParallel on one device (device_ids=[0, 0] is rejected by torch, so replicate by hand like DataParallel.forward
+    does): the replica's forward must use the weights of THIS step."""
+    from torch.nn.parallel import replicate
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    fe = VGG4L(1024).to(DEV).eval()
+    mel = torch.randn(2, 33, 80, device=DEV)
+    with torch.no_grad():
+        outs = []
+        for it in range(3):
+            rep = replicate(fe, [0], detach=True)[0]
+            outs.append((rep(mel), fe(mel)))
+            for p in fe.parameters():
+                p.mul_(1.05)
+            del rep
+        for r, m in outs:
+            assert float((r - m).abs().max()) <= 1e-5 * float(m.abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) > 0
