@@ -663,8 +663,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
-    static int force_tile_kernel = -1;
-    if (force_tile_kernel < 0) force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;
+    static const int force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;   // initialised once, thread-safe
     if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr || row_span != nullptr)) {
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;

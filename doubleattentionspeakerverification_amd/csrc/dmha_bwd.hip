@@ -433,7 +433,12 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
     if (!launched) {
         p.wpu = 4; p.upw = 1; p.arrivals = H;
         const size_t lds = ((size_t)2 * p.t_pad + 2 * dh + 16) * sizeof(float);
-        if (lds > 64 * 1024) return DASV_E_SHAPE;
+        if (lds > 160 * 1024) return DASV_E_SHAPE;   // ~20 k pooled frames on the unaligned correctness path
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_bwd_generic<XT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         dim3 grid((unsigned)(groups8 * H)), block(256);
         hipLaunchKernelGGL((dmha_bwd_generic<XT>), grid, block, lds, stream, p);
         err = hipGetLastError();

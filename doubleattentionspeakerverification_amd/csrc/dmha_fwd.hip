@@ -50,7 +50,8 @@ struct FwdParams {
     int wpu;               // waves cooperating on one unit
     int upw;               // units per workgroup
     int arrivals;          // workgroups per utterance = H / upw
-    int t_pad;             // LDS score row pitch (floats)
+    int t_pad;             // score row pitch (floats)
+    float* s_glob;         // generic kernel, T too long for LDS: [B*H][t_pad] raw scores in the workspace (else null)
     float qscale;          // log2(e) / sqrt(H)
 #ifdef DASV_STAMPS
     unsigned long long* stamps;  // diagnostic build only: [gridDim.x][8] s_memrealtime stamps (100 MHz)
@@ -434,10 +435,16 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
 
 // ---- shape-agnostic kernel: any dh, any alignment, any stride ---------------------------------
 // One 256-thread workgroup per unit; lane <-> frame for the scores, lane <-> feature for the sums.
-// LDS: [t_pad] scores | [16] reductions | [dh] scaled query   (head stage aliases from 0) | flag at the end
-__host__ __device__ inline size_t fwd_lds_generic_floats(int t_pad, int H, int dh) {
-    const size_t a = (size_t)t_pad + 16 + dh, b = fwd_lds_head_floats(H, dh);
+// LDS: [t_pad] scores | [16] reductions | [dh] scaled query   (head stage aliases from 0) | flag at the end.
+// Utterances whose scores do not fit (t_lds = 0) park them in the workspace instead: any length pools, like the
+// reference (poolings.py:73-80 has no length limit).
+__host__ __device__ inline size_t fwd_lds_generic_floats(int t_lds, int H, int dh) {
+    const size_t a = (size_t)t_lds + 16 + dh, b = fwd_lds_head_floats(H, dh);
     return (a > b ? a : b) + 4;
+}
+constexpr size_t kGenericLdsCap = 160 * 1024;
+__host__ inline bool generic_scores_fit_lds(int T, int H, int dh) {
+    return fwd_lds_generic_floats(round_up_i(T, 4), H, dh) * sizeof(float) <= kGenericLdsCap;
 }
 
 template <typename XT>
@@ -451,10 +458,11 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     int len = T;
     if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
 
-    float* s_lds = smem;                       // [t_pad]
-    float* red = smem + p.t_pad;               // [16]
+    const int t_lds = p.s_glob != nullptr ? 0 : p.t_pad;
+    float* s_lds = p.s_glob != nullptr ? p.s_glob + ((size_t)b * H + h) * p.t_pad : smem;   // [t_pad]
+    float* red = smem + t_lds;                 // [16]
     float* qs = red + 16;                      // [dh]
-    int* flag = reinterpret_cast<int*>(smem + fwd_lds_generic_floats(p.t_pad, H, dh) - 4);
+    int* flag = reinterpret_cast<int*>(smem + fwd_lds_generic_floats(t_lds, H, dh) - 4);
 
     for (int d = tid; d < dh; d += nthr) qs[d] = p.query[(size_t)d * H + h] * p.qscale;
     __syncthreads();
@@ -553,6 +561,11 @@ static int largest_divisor_leq(int n, int cap) {
     return 1;
 }
 
+// [round_up(B,64)] arrival counters (zero between launches) | [B][round_up(H,4)] head scores
+static size_t fixed_workspace_bytes(int B, int H) {
+    return (size_t)round_up_i(B, 64) * sizeof(int) + (size_t)B * round_up_i(H, 4) * sizeof(float);
+}
+
 template <typename XT>
 static int fwd_impl(const void* x, const float* query, const float* att, const uint8_t* keep, const int32_t* lengths,
                     float* out, float* align, float* head_w, float* ctx, float* ml, void* workspace,
@@ -574,6 +587,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)round_up_i(B, 64) * sizeof(int));
     p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
+    p.s_glob = nullptr;
     p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
 #ifdef DASV_STAMPS
     p.stamps = g_stamps;
@@ -631,8 +645,18 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     }
     // shape-agnostic path
     p.wpu = 4; p.upw = 1; p.arrivals = H;
-    const size_t lds = fwd_lds_generic_floats(p.t_pad, H, dh) * sizeof(float);
-    if (lds > 160 * 1024) return DASV_E_SHAPE;
+    const bool in_lds = generic_scores_fit_lds(T, H, dh);
+    if (!in_lds) {
+        if (workspace == nullptr || workspace_bytes < dasv_dmha_workspace_bytes(B, T, H, dh)) return DASV_E_WORKSPACE;
+        p.s_glob = reinterpret_cast<float*>(static_cast<char*>(workspace) + fixed_workspace_bytes(B, H));
+    }
+    const size_t lds = fwd_lds_generic_floats(in_lds ? p.t_pad : 0, H, dh) * sizeof(float);
+    if (lds > kGenericLdsCap) return DASV_E_SHAPE;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_fwd_generic<XT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     dim3 grid((unsigned)(groups8 * H)), block(256);
     hipLaunchKernelGGL((dmha_fwd_generic<XT>), grid, block, lds, stream, p);
     snprintf(g_last_variant, sizeof(g_last_variant), "generic<dtype=%d> lds=%zu", XT::kCode, lds);
@@ -659,10 +683,12 @@ const char* dasv_error_string(int code) {
 }
 
 size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh) {
-    (void)T; (void)dh;
     if (B <= 0 || H <= 0) return 0;
     // [round_up(B,64)] arrival counters (must be zero between launches) | [B][round_up(H,4)] head scores
-    return (size_t)dasv::round_up_i(B, 64) * sizeof(int) + (size_t)B * dasv::round_up_i(H, 4) * sizeof(float);
+    // | only for utterances too long for the LDS score row: [B*H][round_up(T,4)] raw scores
+    size_t n = dasv::fixed_workspace_bytes(B, H);
+    if (T > 0 && dh > 0 && !dasv::generic_scores_fit_lds(T, H, dh)) n += (size_t)B * H * dasv::round_up_i(T, 4) * sizeof(float);
+    return n;
 }
 
 int dasv_dmha_workspace_init(void* workspace, size_t workspace_bytes, dasv_stream_t stream) {

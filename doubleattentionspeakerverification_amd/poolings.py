@@ -33,7 +33,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["new_parameter", "Attention", "HeadAttention", "innerKeyValueAttention",
-           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention", "DoubleMHAPlan"]
+           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention", "DoubleMHAPlan", "reset_workspaces"]
 
 
 def new_parameter(*size):
@@ -49,6 +49,14 @@ _fwd_ws = {}
 
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def reset_workspaces():
+    """Re-zero every cached forward workspace (call after a HIP error was seen on a stream or a graph capture was
+    abandoned: the in-launch head exchange relies on its arrival counters being zero between launches)."""
+    with _ws_lock:
+        for buf in _fwd_ws.values():
+            buf.zero_()
 
 
 def _fwd_workspace(device, nbytes):
@@ -116,6 +124,8 @@ def _launch_fwd(x, query, att, head_keep, lengths, want_align):
         rc = lib.dasv_dmha_fwd(_lib.DTYPE_CODES[str(x.dtype).split(".")[-1]], x.data_ptr(), q.data_ptr(), _ptr(a),
                                _ptr(keep), _ptr(lens), _ptr(out), _ptr(align), _ptr(head_w), ctxv.data_ptr(),
                                ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh, sb, st, _stream_ptr(dev))
+        if rc != 0:   # a launch that did not complete may leave arrival counters behind: later launches would never elect
+            lib.dasv_dmha_workspace_init(ws.data_ptr(), ws.numel(), _stream_ptr(dev))   # a last arriver
     _lib.check(rc, "dasv_dmha_fwd")
     return x, q, a, keep, lens, out, align, head_w, ctxv, ml
 
@@ -224,8 +234,15 @@ class DoubleMHAPlan:
             raise RuntimeError("DoubleMHAPlan was built for a %s %s tensor on %s" % ((self.B, self.T, self.D), self.dtype, self.device))
         rc = self._fn(self._code, x.data_ptr(), *self._tail, x.stride(0), x.stride(1), _stream_ptr(self.device))
         if rc != 0:
+            _lib.load().dasv_dmha_workspace_init(self.ws.data_ptr(), self.ws.numel(), _stream_ptr(self.device))
             _lib.check(rc, "dasv_dmha_fwd")
         return self.out, self.align
+
+    def reset(self):
+        """Re-zero the arrival counters (after a HIP error on the stream or an abandoned graph capture: a launch that did
+        not run to completion leaves them non-zero and every later launch would return uninitialised outputs)."""
+        _lib.check(_lib.load().dasv_dmha_workspace_init(self.ws.data_ptr(), self.ws.numel(), _stream_ptr(self.device)),
+                   "dasv_dmha_workspace_init")
 
 
 def _like_input(t, x):

@@ -337,3 +337,20 @@ def test_cabi_argument_errors_are_codes_not_crashes():
     bad[3], bad[6] = a.data_ptr(), out.data_ptr()
     assert lib.dasv_dmha_fwd(*bad) == -3
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("T,H,dh", [(20011, 2, 6), (45003, 2, 6), (45003, 2, 64)])
+def test_very_long_utterances_pool_like_the_reference(T, H, dh):
+    """the reference pools any number of frames.  20 k frames need more than the default 64 KB of dynamic LDS on
+    the shape-agnostic kernel; 45 k frames do not fit the 160 KB at all and park their scores in the workspace."""
+    import oracle
+    from doubleattentionspeakerverification_amd import poolings
+    rs = np.random.RandomState(T)
+    x = rs.standard_normal((2, T, H * dh)).astype(np.float32)
+    q = (rs.standard_normal((dh, H)) * 0.3).astype(np.float32)
+    a = (rs.standard_normal((dh, 1)) * 0.3).astype(np.float32)
+    ref = oracle.dmha_closed(x, q, a)
+    out, align, hw, _ = poolings.double_mha(torch.from_numpy(x).to(DEV), torch.from_numpy(q).to(DEV), torch.from_numpy(a).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref["out"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(align.cpu().numpy(), ref["align"], rtol=2e-3, atol=1e-8)
+    np.testing.assert_allclose(hw.cpu().numpy().reshape(2, H), ref["head_w"].reshape(2, H), rtol=1e-4, atol=1e-6)

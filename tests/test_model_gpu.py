@@ -771,7 +771,6 @@ def test_packed_conv_weights_follow_replicas_and_data_writes():
         b = fe(mel)
         fe.conv42.weight.mul_(2.0)                                    # ordinary in-place update: version moves
         c = fe(mel)
-    assert float((b - 0.5 * a).abs().max()) < 1e-4 * float(a.abs().max()) + 1e-6 or float((b - a).abs().max()) > 0
     assert float((b - a).abs().max()) > 1e-3 * float(a.abs().max())
     assert float((c - b).abs().max()) > 1e-3 * float(b.abs().max())
 
