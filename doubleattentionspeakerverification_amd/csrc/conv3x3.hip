@@ -479,6 +479,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             // fragments before the barrier (the window is unchanged within a slab): 2.5 % slower at 251 registers; 128-pixel
             // tiles with a single weight buffer (<= 80 KB of LDS on maps up to 20 columns, so two workgroups share a CU and
             // desynchronise): 4-7 % slower on those layers (128 registers with spills, more halo and fragment reads per MFMA).
+            // Round 2, same-box A/B against this code (tools/conv_lib_ab.py): a half-tap stagger of waves 4-7 against their
+            // SIMD partners (MI355X_MICROARCH.md, two waves per SIMD, item 9: second-half fragments read before the tap's
+            // barrier and held in registers, their MFMAs issued after it beside the partner's reads; bit-identical results,
+            // 248 registers, no spills): 3-5 % SLOWER on every double-buffered layer with the phases fenced or left to the
+            // scheduler, 6-10 % slower with reads-first hints — the matrix pipe is not waiting for fragment reads here.
             const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
 #pragma unroll
             for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {

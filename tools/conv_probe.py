@@ -21,7 +21,7 @@ def timeit(fn, n=5):
 tot = {"ref": 0, "split": 0, "bf16": 0}
 for name, cin, cout, H, W in layers:
     x = torch.relu(torch.randn(B, cin, H, W, device=dev)).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5)   # leaf Parameter: packed planes are cached
     b = torch.randn(cout, device=dev) * 0.1
     pk = conv.PackedConvWeights()
     with torch.no_grad():
