@@ -522,6 +522,28 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     else finish_if_last<false>(p, b, ticket, smem, flag);
 }
 
+// ---- read floor (measurement aid, not on the product path) --------------------------------------
+// The simplest kernel that reads `nvec` 16-byte vectors once: eight independent loads in flight per thread, grid-stride,
+// one atomic per wave to keep the loads alive.  bench.py times it on the same rotating buffers as the fused kernel: what
+// it needs is the time NO kernel that streams x once can beat on this chip at this size (tools/read_floor.hip swept the
+// grid and depth; 2048 x 256 threads, depth 8 was the fastest on 39 MB).
+__global__ void __launch_bounds__(256) read_floor_kernel(const float4* __restrict__ x, long long nvec, float* __restrict__ out) {
+    constexpr int DEPTH = 8;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i + (DEPTH - 1) * stride < nvec; i += DEPTH * stride) {
+        float4 v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) v[k] = x[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    for (; i < nvec; i += stride) acc += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, acc);
+}
+
 // ---- host side --------------------------------------------------------------------------------
 struct Tuning { int nw = 0, wpu = 0, lds_pad = 0, force_generic = 0, rows = 0; };
 #ifdef DASV_STAMPS
@@ -739,6 +761,14 @@ void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_
 }
 
 const char* dasv_debug_last_variant(void) { return dasv::g_last_variant; }
+
+int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream) {
+    if (x == nullptr || scratch == nullptr) return DASV_E_NULL;
+    if (bytes < 16 || (uintptr_t)x % 16 != 0) return DASV_E_SHAPE;
+    hipLaunchKernelGGL(dasv::read_floor_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float4*>(x), (long long)(bytes / 16), scratch);
+    return (int)hipGetLastError();
+}
 
 #ifdef DASV_STAMPS
 void dasv_debug_set_stamps(void* p) { dasv::g_stamps = static_cast<unsigned long long*>(p); }

@@ -237,6 +237,10 @@ void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_
                            int rows_per_pass);
 /* name of the kernel variant the last dasv_dmha_fwd call on this thread selected */
 const char* dasv_debug_last_variant(void);
+/* Measurement aid: reads `bytes` (16-byte aligned, whole 16-byte vectors) at x once with the simplest possible kernel and
+ * adds per-wave sums into scratch[0..2047] (>= 2048 floats, caller-zeroed).  bench.py times it beside the fused pooling
+ * kernel: no kernel that streams x once can be faster than this on the same buffers. */
+int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream);
 
 #ifdef __cplusplus
 }
