@@ -100,6 +100,14 @@ class _VGG(nn.Module):
                 and c11.out_channels % 4 == 0 and 256 % (c11.out_channels // 4) == 0 and c11.out_channels <= 1024)
 
     def forward(self, paddedInputTensor):
+        h = self.forward_map(paddedInputTensor)
+        # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
+        return h.permute(0, 2, 1, 3).reshape(h.size(0), h.size(2), h.size(1) * h.size(3))
+
+    def forward_map(self, paddedInputTensor):
+        """The front-end up to, not including, the final transpose/contiguous/view (CNNs.py:49-50 / 88-89): the
+        [B, C, T', F'] map (channels_last memory on the HIP path).  The pooling kernels can read it in place
+        (poolings.nhwc_frames_supported), which is how SpeakerClassifier uses it."""
         B, T, Fdim = paddedInputTensor.shape
         hip = self._hip_front(paddedInputTensor)
         grad = torch.is_grad_enabled()
@@ -141,8 +149,7 @@ class _VGG(nn.Module):
                 h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2) if grad else _hipconv.maxpool2x2_ceil(h)
             else:
                 h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
-        # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
-        return h.permute(0, 2, 1, 3).reshape(B, h.size(2), h.size(1) * h.size(3))
+        return h
 
 
 class VGG3L(_VGG):

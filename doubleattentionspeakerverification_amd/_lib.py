@@ -51,6 +51,9 @@ SIGNATURES = {
     "dasv_maxpool2x2_bwd_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_dmha_nhwc_supported": (c_int, [c_int, c_int, c_int]),
+    "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_dmha_bwd_nhwc_f32": (c_int, [c_void_p] * 12 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_debug_last_variant": (ctypes.c_char_p, []),
     "dasv_debug_read_floor": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),

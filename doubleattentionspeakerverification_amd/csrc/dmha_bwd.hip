@@ -32,6 +32,7 @@ struct BwdParams {
     float* gu;              // [B][H]
     float* part_a;          // [B*arrivals][dh] per-workgroup partial sums of gu*c (vector kernel) / [B*H][dh] (generic)
     long long sb, st;
+    long long seg;          // NHWC frames (PERM kernels): element stride between the F' segments of a frame (= channels C)
     int B, T, H, dh;
     int wpu, upw, arrivals;
     int t_pad;
@@ -46,12 +47,19 @@ __device__ __forceinline__ bool bwd_block_to_unit(int arrivals, int B, int& b, i
     return b < B;
 }
 
-template <typename XT, int G, int NI, int R>
+// PERM: x / grad_x are the front-end's NHWC map [B, T', F', C]; same re-addressing as in the forward kernel (dmha_fwd.hip)
+template <bool PERM, int G, int NI, int EPV>
+__device__ __forceinline__ int bwd_feat_of(int c, int j, int e) {
+    return PERM ? (c * EPV + e) * NI + j : (c + G * j) * EPV + e;
+}
+
+template <typename XT, int G, int NI, int R, bool PERM = false>
 __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using E = Elem<XT>;
     constexpr int EPV = E::kPerVec;
     constexpr int GPW = 64 / G;
+    const size_t vec_step = PERM ? (size_t)p.seg * E::kBytes : (size_t)G * 16;
 
     int b, a;
     if (!bwd_block_to_unit(p.arrivals, p.B, b, a)) return;
@@ -65,7 +73,7 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
     int len = T;
     if (p.lengths != nullptr) len = max(0, min(T, p.lengths[b]));
 
-    const size_t unit_off = ((size_t)b * p.sb + (size_t)h * dh) * E::kBytes + (size_t)c * 16;
+    const size_t unit_off = ((size_t)b * p.sb + (size_t)h * (PERM ? G * EPV : dh)) * E::kBytes + (size_t)c * 16;
     const char* xrow = static_cast<const char*>(p.x) + unit_off;
     char* gxrow = static_cast<char*>(p.gx) + unit_off;
     const size_t row_bytes = (size_t)p.st * E::kBytes;
@@ -88,7 +96,7 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * G * 16);
+                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * vec_step);
                 buf[i][j] = v;
             }
         }
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
-                const int col = (c + G * j) * EPV + e;
+                const int col = bwd_feat_of<PERM, G, NI, EPV>(c, j, e);
                 q[j][e] = p.query[(size_t)col * H + h];
                 cfrag[j][e] = ch[col];
             }
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
-                    const int col = (c + G * j) * EPV + e;
+                    const int col = bwd_feat_of<PERM, G, NI, EPV>(c, j, e);
                     gof[j][e] = p.go[(size_t)b * dh + col];
                     gwp = fmaf(gof[j][e], cfrag[j][e], gwp);
                     gdp = fmaf(gof[j][e], p.out[(size_t)b * dh + col], gdp);
@@ -133,12 +141,12 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) gc[j][e] = wh * gof[j][e] + guh * p.att[(c + G * j) * EPV + e];
+                for (int e = 0; e < EPV; ++e) gc[j][e] = wh * gof[j][e] + guh * p.att[bwd_feat_of<PERM, G, NI, EPV>(c, j, e)];
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) gc[j][e] = p.go[((size_t)b * H + h) * dh + (c + G * j) * EPV + e];
+                for (int e = 0; e < EPV; ++e) gc[j][e] = p.go[((size_t)b * H + h) * dh + bwd_feat_of<PERM, G, NI, EPV>(c, j, e)];
         }
         float part = 0.f;
 #pragma unroll
@@ -180,7 +188,7 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
                         o[e] = fmaf(pr, gc[j][e], gsr * q[j][e]);
                         gq[j][e] = fmaf(gs, f[j][e], gq[j][e]);
                     }
-                    *reinterpret_cast<uint4*>(wp + (size_t)j * G * 16) = E::pack(o);
+                    *reinterpret_cast<uint4*>(wp + (size_t)j * vec_step) = E::pack(o);
                 }
             }
         }
@@ -202,10 +210,16 @@ __global__ void __launch_bounds__(512) dmha_bwd_vec(const BwdParams p) {
         float* rs = red + (size_t)(uu * P + phase) * dh;
         typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j) {
+            if constexpr (PERM) {
 #pragma unroll
-            for (int e = 0; e < EPV; e += 4)
-                *reinterpret_cast<f4*>(rs + (c + G * j) * EPV + e) = f4{gq[j][e], gq[j][e + 1], gq[j][e + 2], gq[j][e + 3]};
+                for (int e = 0; e < EPV; ++e) rs[bwd_feat_of<true, G, NI, EPV>(c, j, e)] = gq[j][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4)
+                    *reinterpret_cast<f4*>(rs + (c + G * j) * EPV + e) = f4{gq[j][e], gq[j][e + 1], gq[j][e + 2], gq[j][e + 3]};
+            }
+        }
     }
     __syncthreads();
     if (wu == 0) {
@@ -357,6 +371,13 @@ static hipError_t launch_bwd_vec(const BwdParams& p, dim3 grid, dim3 block, size
     return hipGetLastError();
 }
 
+static bool dispatch_bwd_vec_nhwc(int G, int NI, const BwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
+#define DASV_CASE(g) if (G == g && NI == 5) { hipLaunchKernelGGL((dmha_bwd_vec<F32, g, 5, 1, true>), grid, block, lds, s, p); err = hipGetLastError(); return true; }
+    DASV_CASE(4) DASV_CASE(8) DASV_CASE(16)
+#undef DASV_CASE
+    return false;
+}
+
 template <typename XT>
 static bool dispatch_bwd_vec(int G, int NI, const BwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
 #define DASV_CASE(g, n) if (G == g && NI == n) { err = launch_bwd_vec<XT, g, n>(p, grid, block, lds, s); return true; }
@@ -377,7 +398,7 @@ template <typename XT>
 static int bwd_impl(const void* x, const float* query, const float* att, const int32_t* lengths, const float* head_w,
                     const float* ctx, const float* ml, const float* out, const float* go, void* gx, float* grad_query,
                     float* grad_att, void* workspace, size_t workspace_bytes, int B, int T, int H, int dh, int64_t sb,
-                    int64_t st, hipStream_t stream) {
+                    int64_t st, hipStream_t stream, int perm_f = 0, int64_t seg = 0) {
     using E = Elem<XT>;
     if (x == nullptr || query == nullptr || ctx == nullptr || ml == nullptr || go == nullptr || gx == nullptr ||
         grad_query == nullptr)
@@ -394,7 +415,7 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
     p.part_q = static_cast<float*>(workspace);
     p.part_a = p.part_q + (size_t)B * H * dh;
     p.gu = p.part_a + (size_t)B * H * dh;
-    p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
+    p.sb = sb; p.st = st; p.seg = seg; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
     p.rs = (float)(1.0 / sqrt((double)H));
@@ -402,7 +423,13 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
     const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)gx % 16 == 0) && ((sb * E::kBytes) % 16 == 0) &&
                          ((st * E::kBytes) % 16 == 0) && (dh % E::kPerVec == 0);
     int G = 0, NI = 0;
-    if (aligned) {
+    if (perm_f > 0) {
+        const int cph = dh / perm_f;
+        if (!aligned || cph * perm_f != dh || cph % E::kPerVec != 0 || (seg * E::kBytes) % 16 != 0) return DASV_E_SHAPE;
+        G = cph / E::kPerVec;
+        NI = perm_f;
+        if (!(G == 4 || G == 8 || G == 16) || NI != 5 || XT::kCode != 0) return DASV_E_SHAPE;
+    } else if (aligned) {
         const int vecs = dh / E::kPerVec;
         G = 16;
         while (G > 1 && vecs % G != 0) G >>= 1;
@@ -427,9 +454,11 @@ static int bwd_impl(const void* x, const float* query, const float* att, const i
         const size_t lds = ((size_t)upw * wpu * gpw * dh + 8) * sizeof(float);
         if (lds <= 64 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
-            launched = dispatch_bwd_vec<XT>(G, NI, p, grid, block, lds, stream, err);
+            launched = perm_f > 0 ? dispatch_bwd_vec_nhwc(G, NI, p, grid, block, lds, stream, err)
+                                  : dispatch_bwd_vec<XT>(G, NI, p, grid, block, lds, stream, err);
         }
     }
+    if (!launched && perm_f > 0) return DASV_E_SHAPE;
     if (!launched) {
         p.wpu = 4; p.upw = 1; p.arrivals = H;
         const size_t lds = ((size_t)2 * p.t_pad + 2 * dh + 16) * sizeof(float);
@@ -487,6 +516,17 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
         default:
             return DASV_E_DTYPE;
     }
+}
+
+int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att, const int32_t* lengths, const float* head_w,
+                           const float* ctx, const float* ml, const float* out, const float* grad_out, float* grad_x,
+                           float* grad_query, float* grad_att, void* workspace, size_t workspace_bytes, int B, int T, int F,
+                           int C, int H, dasv_stream_t stream) {
+    if (F != 5 || C <= 0 || H <= 0 || C % H != 0) return DASV_E_SHAPE;
+    const int dh = C / H * F;
+    return dasv::bwd_impl<dasv::F32>(x, query, att, lengths, head_w, ctx, ml, out, grad_out, grad_x, grad_query, grad_att,
+                                     workspace, workspace_bytes, B, T, H, dh, (int64_t)T * F * C, (int64_t)F * C,
+                                     (hipStream_t)stream, F, (int64_t)C);
 }
 
 }  // extern "C"

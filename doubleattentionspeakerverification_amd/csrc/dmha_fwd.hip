@@ -46,6 +46,7 @@ struct FwdParams {
     int* counters;         // [B] arrival counters (zero between launches)
     float* exch_u;         // [B][round_up(H,4)] head scores <c_h, att>, published beside ctx
     long long sb, st;      // element strides of x
+    long long seg;         // NHWC frames (PERM kernels): element stride between the F' segments of a frame (= channels C)
     int B, T, H, dh;
     int wpu;               // waves cooperating on one unit
     int upw;               // units per workgroup
@@ -214,7 +215,17 @@ __device__ __forceinline__ void finish_if_last(const FwdParams& p, int b, int ti
 }
 
 // ---- the streaming kernel ---------------------------------------------------------------------
-template <typename XT, int G, int NI, int R>
+// PERM: x is the front-end's own NHWC map [B, T', F', C] (CNNs.py:88-89's transpose/contiguous/view folded into the
+// addressing).  The reference's feature index is d = c*F' + f, so head h owns channels [h*C/H, (h+1)*C/H) of every one of
+// the F' = NI segments of a frame: vector j of a lane is 16 bytes of segment f = j (G = C/H/4 lanes per segment), and
+// element e of it is feature (4*c + e)*F' + j of the head.  Only the addresses and the gathers of q / the LDS parking
+// change; everything after the parking works on the reference's feature order.
+template <bool PERM, int G, int NI, int EPV>
+__device__ __forceinline__ int feat_of(int c, int j, int e) {
+    return PERM ? (c * EPV + e) * NI + j : (c + G * j) * EPV + e;
+}
+
+template <typename XT, int G, int NI, int R, bool PERM = false>
 __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using E = Elem<XT>;
@@ -222,6 +233,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     constexpr int GPW = 64 / G;
     constexpr int DH = G * NI * EPV;
     constexpr int ND = (DH + 63) / 64;
+    const size_t vec_step = PERM ? (size_t)p.seg * E::kBytes : (size_t)G * 16;   // bytes between a lane's vectors j, j+1
 
     int b, a;
     if (!block_to_unit(p.arrivals, p.B, b, a)) return;
@@ -242,7 +254,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     int* flag = reinterpret_cast<int*>(smem + fwd_lds_floats(upw, p.t_pad, wpu, P, H, DH) - 4);
 
     const char* xrow = static_cast<const char*>(p.x) +
-                       ((size_t)b * p.sb + (size_t)h * DH) * E::kBytes + (size_t)c * 16;
+                       ((size_t)b * p.sb + (size_t)h * (PERM ? G * EPV : DH)) * E::kBytes + (size_t)c * 16;
     const size_t row_bytes = (size_t)p.st * E::kBytes;
     const int rows_per_pass = P * R;
     const int npass = (len + rows_per_pass - 1) / rows_per_pass;
@@ -256,7 +268,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * G * 16);
+                if (valid) v = *reinterpret_cast<const uint4*>(rp + (size_t)j * vec_step);
                 buf[i][j] = v;
             }
         }
@@ -272,7 +284,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)((c + G * j) * EPV + e) * H + h];
+        for (int e = 0; e < EPV; ++e) q[j][e] = p.query[(size_t)feat_of<PERM, G, NI, EPV>(c, j, e) * H + h];
     if (npass > 1) load_pass(bufB, 1);
     float attv[ND];
 #pragma unroll
@@ -362,11 +374,17 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         float* ra = red_acc + (size_t)(uu * P + phase) * DH;
         typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j) {
+            if constexpr (PERM) {
 #pragma unroll
-            for (int e = 0; e < EPV; e += 4)
-                *reinterpret_cast<f4*>(ra + (c + G * j) * EPV + e) =
-                    f4{acc[j][e] * sc, acc[j][e + 1] * sc, acc[j][e + 2] * sc, acc[j][e + 3] * sc};
+                for (int e = 0; e < EPV; ++e) ra[feat_of<true, G, NI, EPV>(c, j, e)] = acc[j][e] * sc;
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4)
+                    *reinterpret_cast<f4*>(ra + (c + G * j) * EPV + e) =
+                        f4{acc[j][e] * sc, acc[j][e + 1] * sc, acc[j][e + 2] * sc, acc[j][e + 3] * sc};
+            }
+        }
     }
     __syncthreads();
 
@@ -554,15 +572,23 @@ static thread_local char g_last_variant[96] = "none";
 
 constexpr int rows_per_pass_for(int ni) { return ni == 1 ? 4 : (ni <= 3 ? 2 : 1); }
 
-template <typename XT, int G, int NI, int R>
+template <typename XT, int G, int NI, int R, bool PERM = false>
 static hipError_t launch_vec(const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_fwd_vec<XT, G, NI, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dmha_fwd_vec<XT, G, NI, R, PERM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dmha_fwd_vec<XT, G, NI, R>), grid, block, lds, s, p);
+    hipLaunchKernelGGL((dmha_fwd_vec<XT, G, NI, R, PERM>), grid, block, lds, s, p);
     return hipGetLastError();
+}
+
+// NHWC frames: fp32 maps of the VGG4L front-end (F' = 5 segments per frame), 16 / 32 / 64 channels per head
+static bool dispatch_vec_nhwc(int G, int NI, const FwdParams& p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipError_t& err) {
+#define DASV_CASE(g) if (G == g && NI == 5) { err = launch_vec<F32, g, 5, 1, true>(p, grid, block, lds, s); return true; }
+    DASV_CASE(4) DASV_CASE(8) DASV_CASE(16)
+#undef DASV_CASE
+    return false;
 }
 
 // (G, NI) -> kernel; R (rows per lane per pass) defaults per NI, a few alternatives exist for sweeps.
@@ -591,7 +617,8 @@ static size_t fixed_workspace_bytes(int B, int H) {
 template <typename XT>
 static int fwd_impl(const void* x, const float* query, const float* att, const uint8_t* keep, const int32_t* lengths,
                     float* out, float* align, float* head_w, float* ctx, float* ml, void* workspace,
-                    size_t workspace_bytes, int B, int T, int H, int dh, int64_t sb, int64_t st, hipStream_t stream) {
+                    size_t workspace_bytes, int B, int T, int H, int dh, int64_t sb, int64_t st, hipStream_t stream,
+                    int perm_f = 0, int64_t seg = 0) {
     using E = Elem<XT>;
     if (x == nullptr || query == nullptr || ctx == nullptr) return DASV_E_NULL;
     if (att != nullptr && out == nullptr) return DASV_E_NULL;
@@ -607,7 +634,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     p.out = out; p.align = align; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
     p.counters = static_cast<int*>(workspace);
     p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)round_up_i(B, 64) * sizeof(int));
-    p.sb = sb; p.st = st; p.B = B; p.T = T; p.H = H; p.dh = dh;
+    p.sb = sb; p.st = st; p.seg = seg; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.s_glob = nullptr;
     p.qscale = (float)(1.4426950408889634 / sqrt((double)H));
@@ -619,7 +646,14 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     const bool aligned = ((uintptr_t)x % 16 == 0) && ((sb * E::kBytes) % 16 == 0) && ((st * E::kBytes) % 16 == 0) &&
                          (dh % E::kPerVec == 0);
     int G = 0, NI = 0;
-    if (aligned && !g_tuning.force_generic) {
+    if (perm_f > 0) {
+        // NHWC frames: G lanes x 16 bytes = one head's channels of one segment, NI = segments per frame
+        const int cph = dh / perm_f;
+        if (!aligned || cph * perm_f != dh || cph % E::kPerVec != 0 || (seg * E::kBytes) % 16 != 0) return DASV_E_SHAPE;
+        G = cph / E::kPerVec;
+        NI = perm_f;
+        if (!(G == 4 || G == 8 || G == 16) || NI != 5 || XT::kCode != 0) return DASV_E_SHAPE;
+    } else if (aligned && !g_tuning.force_generic) {
         const int vecs = dh / E::kPerVec;
         G = 16;
         while (G > 1 && vecs % G != 0) G >>= 1;
@@ -655,16 +689,22 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
         if (lds <= 160 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
             hipError_t err = hipSuccess;
-            bool ok = g_tuning.rows > 0 && dispatch_vec<XT>(G, NI, g_tuning.rows, p, grid, block, lds, stream, err);
-            if (ok) R = g_tuning.rows;
-            if (!ok) ok = dispatch_vec<XT>(G, NI, R, p, grid, block, lds, stream, err);
+            bool ok = false;
+            if (perm_f > 0) {
+                ok = dispatch_vec_nhwc(G, NI, p, grid, block, lds, stream, err);
+            } else {
+                ok = g_tuning.rows > 0 && dispatch_vec<XT>(G, NI, g_tuning.rows, p, grid, block, lds, stream, err);
+                if (ok) R = g_tuning.rows;
+                if (!ok) ok = dispatch_vec<XT>(G, NI, R, p, grid, block, lds, stream, err);
+            }
             if (ok) {
-                snprintf(g_last_variant, sizeof(g_last_variant), "vec<dtype=%d,G=%d,NI=%d,R=%d> nw=%d wpu=%d upw=%d lds=%zu",
-                         XT::kCode, G, NI, R, nw, wpu, upw, lds);
+                snprintf(g_last_variant, sizeof(g_last_variant), "vec<dtype=%d,G=%d,NI=%d,R=%d%s> nw=%d wpu=%d upw=%d lds=%zu",
+                         XT::kCode, G, NI, R, perm_f > 0 ? ",nhwc" : "", nw, wpu, upw, lds);
                 return (int)err;
             }
         }
     }
+    if (perm_f > 0) return DASV_E_SHAPE;   // no shape-agnostic form of the NHWC addressing: the caller permutes instead
     // shape-agnostic path
     p.wpu = 4; p.upw = 1; p.arrivals = H;
     const bool in_lds = generic_scores_fit_lds(T, H, dh);
@@ -750,6 +790,21 @@ DASV_TYPED(dasv_dmha_fwd_f32, DASV_F32, const float*)
 DASV_TYPED(dasv_dmha_fwd_bf16, DASV_BF16, const void*)
 DASV_TYPED(dasv_dmha_fwd_f16, DASV_F16, const void*)
 #undef DASV_TYPED
+
+int dasv_dmha_nhwc_supported(int F, int C, int H) {
+    if (F != 5 || C <= 0 || H <= 0 || C % H != 0) return 0;
+    const int cph = C / H;
+    return cph == 16 || cph == 32 || cph == 64;
+}
+
+int dasv_dmha_fwd_nhwc_f32(const float* x, const float* query, const float* att, const uint8_t* head_keep,
+                           const int32_t* lengths, float* out, float* align, float* head_w, float* ctx, float* ml,
+                           void* workspace, size_t workspace_bytes, int B, int T, int F, int C, int H, dasv_stream_t stream) {
+    if (!dasv_dmha_nhwc_supported(F, C, H)) return DASV_E_SHAPE;
+    const int dh = C / H * F;
+    return dasv::fwd_impl<dasv::F32>(x, query, att, head_keep, lengths, out, align, head_w, ctx, ml, workspace, workspace_bytes,
+                                     B, T, H, dh, (int64_t)T * F * C, (int64_t)F * C, (hipStream_t)stream, F, (int64_t)C);
+}
 
 void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic,
                            int rows_per_pass) {

@@ -72,11 +72,14 @@ class SpeakerClassifier(nn.Module):
                                                m=parameters.marginFactor, annealing=parameters.annealing)
 
     def _utterance_vector(self, x):
-        frames = self.front_end(x)
         pool = self.poolingLayer
         if isinstance(pool, _pool.DoubleMHA):
+            fmap = self.front_end.forward_map(x)
+            if _pool.nhwc_frames_supported(fmap, pool.heads_number):
+                return pool.pool_map(fmap)     # the fused launch reads the NHWC map in place: no transposing copy
+            frames = fmap.permute(0, 2, 1, 3).reshape(fmap.size(0), fmap.size(2), fmap.size(1) * fmap.size(3))
             return pool.pool(frames)           # same launch as forward(), alignments skipped
-        return pool(frames)[0]
+        return pool(self.front_end(x))[0]
 
     def getEmbedding(self, x):
         hidden = F.relu(self.fc1(self._utterance_vector(x)))

@@ -33,7 +33,8 @@ from torch import nn
 from . import _lib
 
 __all__ = ["new_parameter", "Attention", "HeadAttention", "innerKeyValueAttention",
-           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention", "DoubleMHAPlan", "reset_workspaces"]
+           "MultiHeadAttention", "DoubleMHA", "double_mha", "multi_head_attention", "DoubleMHAPlan", "reset_workspaces",
+           "nhwc_frames_supported"]
 
 
 def new_parameter(*size):
@@ -151,6 +152,96 @@ def _launch_bwd(x, q, a, lens, head_w, ctxv, ml, out, go):
                                B, T, H, dh, sb, st, _stream_ptr(dev))
     _lib.check(rc, "dasv_dmha_bwd")
     return gx, gq, ga
+
+
+def nhwc_frames_supported(h4, heads):
+    """True when `h4` — a front-end map [B, C, T', F'] fp32 in channels_last memory ([B][T'][F'][C]) — can be pooled in place:
+    the reference's frame vector is `h4.transpose(1, 2).contiguous().view(B, T', C*F')` (CNNs.py:88-89, feature c*F' + f)."""
+    if h4.dim() != 4 or not h4.is_cuda or h4.dtype != torch.float32:
+        return False
+    B, C, T, F = h4.shape
+    if h4.stride() != (T * F * C, 1, F * C, C):
+        return False
+    return bool(_lib.load().dasv_dmha_nhwc_supported(F, C, heads))
+
+
+def _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align):
+    lib = _lib.load()
+    B, C, T, F = h4.shape
+    dh, H = query.shape
+    if C * F != dh * H:
+        raise RuntimeError("feature size %d does not match query %s" % (C * F, tuple(query.shape)))
+    dev = h4.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    q = query.detach().to(**f32).contiguous()
+    a = None if att is None else att.detach().to(**f32).contiguous().view(-1)
+    keep = None
+    if head_keep is not None:
+        keep = head_keep.to(device=dev, dtype=torch.uint8).contiguous()
+        if tuple(keep.shape) != (B, H):
+            raise RuntimeError("head_keep must be [B,H]")
+    lens = None
+    if lengths is not None:
+        lens = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
+        if tuple(lens.shape) != (B,):
+            raise RuntimeError("lengths must be [B]")
+    ctxv = torch.empty(B, H, dh, **f32)
+    ml = torch.empty(B, H, 2, **f32)
+    align = torch.empty(B, T, H, **f32) if want_align else None
+    out = torch.empty(B, dh, **f32) if a is not None else None
+    head_w = torch.empty(B, H, **f32) if a is not None else None
+    ws = _fwd_workspace(dev, lib.dasv_dmha_workspace_bytes(B, T, H, dh))
+    with torch.cuda.device(dev):
+        rc = lib.dasv_dmha_fwd_nhwc_f32(h4.data_ptr(), q.data_ptr(), _ptr(a), _ptr(keep), _ptr(lens), _ptr(out), _ptr(align),
+                                        _ptr(head_w), ctxv.data_ptr(), ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, F, C, H,
+                                        _stream_ptr(dev))
+        if rc != 0:
+            lib.dasv_dmha_workspace_init(ws.data_ptr(), ws.numel(), _stream_ptr(dev))
+    _lib.check(rc, "dasv_dmha_fwd_nhwc_f32")
+    return q, a, lens, out, align, head_w, ctxv, ml
+
+
+class _PoolNHWCFn(torch.autograd.Function):
+    """The fused pooling on the front-end's own NHWC map (no transposing copy, forward or backward): h4 [B,C,T',F']
+    channels_last, query, att(optional) -> (out | ctx, align).  The gradient comes back as a channels_last map."""
+
+    @staticmethod
+    def forward(ctx, h4, query, att, head_keep, lengths, want_align):
+        q, a, lens, out, align, head_w, ctxv, ml = _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align)
+        ctx.save_for_backward(h4, q, a, lens, head_w, ctxv, ml, out)
+        ctx.q_dtype = query.dtype
+        ctx.a_meta = None if att is None else (att.dtype, att.shape)
+        B, H, dh = ctxv.shape
+        if align is None:
+            align = torch.empty(0, device=h4.device)
+        primary = out if a is not None else ctxv.view(B, H * dh)
+        ctx.mark_non_differentiable(align)
+        return primary, align
+
+    @staticmethod
+    def backward(ctx, g_primary, _g_align):
+        h4, q, a, lens, head_w, ctxv, ml, out = ctx.saved_tensors
+        lib = _lib.load()
+        B, C, T, F = h4.shape
+        dh, H = q.shape
+        dev = h4.device
+        gx = torch.empty_like(h4, memory_format=torch.channels_last)
+        if gx.stride() != h4.stride():
+            gx = torch.empty_strided(h4.shape, h4.stride(), dtype=h4.dtype, device=dev)
+        gq = torch.empty(dh, H, dtype=torch.float32, device=dev)
+        ga = torch.empty(dh, 1, dtype=torch.float32, device=dev) if a is not None else None
+        nbytes = lib.dasv_dmha_bwd_workspace_bytes(B, T, H, dh)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        go = g_primary.to(dtype=torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.dasv_dmha_bwd_nhwc_f32(h4.data_ptr(), q.data_ptr(), _ptr(a), _ptr(lens), _ptr(head_w), ctxv.data_ptr(),
+                                            ml.data_ptr(), _ptr(out), go.data_ptr(), gx.data_ptr(), gq.data_ptr(), _ptr(ga),
+                                            ws.data_ptr(), ws.numel(), B, T, F, C, H, _stream_ptr(dev))
+        _lib.check(rc, "dasv_dmha_bwd_nhwc_f32")
+        gq = gq.to(ctx.q_dtype)
+        if ga is not None:
+            ga = ga.to(ctx.a_meta[0]).view(ctx.a_meta[1])
+        return gx, gq, ga, None, None, None
 
 
 class _PoolFn(torch.autograd.Function):
@@ -354,3 +445,14 @@ class DoubleMHA(nn.Module):
         """forward() without materialising the [B,T,H] alignments (what the model needs)."""
         out, _, _, _ = self._run(x, head_keep, lengths, False)
         return _like_input(out, x)
+
+    def pool_map(self, h4, head_keep=None, lengths=None, want_align=False):
+        """pool() / forward() straight from the front-end's [B,C,T',F'] channels_last map (see nhwc_frames_supported):
+        the frame vectors [B,T',C*F'] of CNNs.py:88-89 are never materialised.  Returns out, or (out, alignment)."""
+        if self.training and head_keep is None:
+            head_keep = self.headsAttention.draw_head_keep(h4.size(0), self.heads_number, h4.device)
+        out, align = _PoolNHWCFn.apply(h4, self.utteranceAttention.query, self.headsAttention.att, head_keep, lengths, want_align)
+        if want_align:
+            self.utteranceAttention.alignment = align
+            return out, align
+        return out

@@ -226,6 +226,23 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * The same two launches on the front-end's own NHWC map: x / grad_x are [B, T, F, C] fp32 (what a channels_last
+ * [B, C, T, F] tensor is in memory), i.e. the reference's `transpose(1, 2).contiguous().view(B, T, C*F)` (CNNs.py:88-89)
+ * is folded into the kernels' addressing: feature d = c*F + f, D = C*F, dh = D / H = (C/H)*F.  All other tensors
+ * (query [dh,H], att, out, align, head_w, ctx, ml, gradients of query / att) are exactly those of dasv_dmha_fwd / _bwd.
+ * dasv_dmha_nhwc_supported: 1 for F == 5 (VGG4L on 80 mel bins) with 16, 32 or 64 channels per head; callers permute
+ * and use dasv_dmha_fwd otherwise.  Workspaces: dasv_dmha_workspace_bytes / dasv_dmha_bwd_workspace_bytes of (B,T,H,dh).
+ * ------------------------------------------------------------------------ */
+int dasv_dmha_nhwc_supported(int F, int C, int H);
+int dasv_dmha_fwd_nhwc_f32(const float* x, const float* query, const float* att, const uint8_t* head_keep,
+                           const int32_t* lengths, float* out, float* align, float* head_w, float* ctx, float* ml,
+                           void* workspace, size_t workspace_bytes, int B, int T, int F, int C, int H, dasv_stream_t stream);
+int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att, const int32_t* lengths, const float* head_w,
+                           const float* ctx, const float* ml, const float* out, const float* grad_out, float* grad_x,
+                           float* grad_query, float* grad_att, void* workspace, size_t workspace_bytes, int B, int T, int F,
+                           int C, int H, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts
  * cooperating on one (utterance, head) (0 = auto); lds_pad_bytes: extra LDS per

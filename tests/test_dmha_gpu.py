@@ -354,3 +354,56 @@ def test_very_long_utterances_pool_like_the_reference(T, H, dh):
     np.testing.assert_allclose(out.cpu().numpy(), ref["out"], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(align.cpu().numpy(), ref["align"], rtol=2e-3, atol=1e-8)
     np.testing.assert_allclose(hw.cpu().numpy().reshape(2, H), ref["head_w"].reshape(2, H), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,C,H", [(3, 19, 512, 32), (5, 19, 1024, 32), (2, 7, 1024, 16), (9, 50, 256, 16)])
+def test_nhwc_map_is_pooled_in_place_like_the_transposed_frames(B, T, C, H):
+    """CNNs.py:88-89 folded into the kernels' addressing: pooling the front-end's [B,C,T',F'] channels_last map in place
+    (forward and backward) must equal pooling the materialised [B,T',C*F'] frames, and the closed-form oracle."""
+    import oracle
+    pool = _pool()
+    F = 5
+    dh = C * F // H
+    rs = np.random.RandomState(C + T)
+    frames = rs.standard_normal((B, T, C * F)).astype(np.float32)            # reference order: feature = c*F + f
+    q = (rs.standard_normal((dh, H)) * 0.2).astype(np.float32)
+    a = (rs.standard_normal((dh, 1)) * 0.2).astype(np.float32)
+    go = rs.standard_normal((B, dh)).astype(np.float32)
+    keep = rs.randint(0, 4, size=(B, H)) > 0
+    keep[:, 0] = True
+    lens = rs.randint(1, T + 1, size=B).astype(np.int32)
+    lens[0] = T
+    # the same numbers as a [B,C,T,F] map in channels_last memory
+    h4 = _t(frames).view(B, T, C, F).permute(0, 2, 1, 3).contiguous(memory_format=torch.channels_last)
+    assert h4.stride() == (T * F * C, 1, F * C, C)
+    assert pool.nhwc_frames_supported(h4, H)
+    mod = _module(C * F, H, q, a)
+    mod.train()
+    res = {}
+    for tag in ("map", "frames"):
+        qt = mod.utteranceAttention.query
+        at = mod.headsAttention.att
+        for p_ in (qt, at):
+            p_.grad = None
+        if tag == "map":
+            x = h4.clone().requires_grad_(True)
+            out, al = mod.pool_map(x, head_keep=_t(keep, torch.bool), lengths=_t(lens, torch.int32), want_align=True)
+            assert "nhwc" in _lib().dasv_debug_last_variant().decode()
+        else:
+            x = _t(frames).requires_grad_(True)
+            out, al = mod(x, head_keep=_t(keep, torch.bool), lengths=_t(lens, torch.int32))
+        (out * _t(go)).sum().backward()
+        gx = x.grad
+        if tag == "map":
+            assert gx.stride() == h4.stride()
+            gx = gx.permute(0, 2, 1, 3).reshape(B, T, C * F)
+        res[tag] = [v.detach().cpu().numpy() for v in (out, al, gx, qt.grad, at.grad)]
+    for k, (m, f) in enumerate(zip(res["map"], res["frames"])):
+        np.testing.assert_allclose(m, f, rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(f).max())), err_msg=str(k))
+    # and against the oracle, utterance by utterance at its own length
+    for b in range(B):
+        n = int(lens[b])
+        ref = oracle.dmha_closed(frames[b:b + 1, :n], q, a, head_keep=keep[b:b + 1])
+        np.testing.assert_allclose(res["map"][0][b], ref["out"][0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(res["map"][1][b, :n], ref["align"][0], rtol=0, atol=1e-6)
+        assert float(np.abs(res["map"][1][b, n:]).max(initial=0.0)) == 0.0
