@@ -31,6 +31,8 @@ SIGNATURES = {
     "dasv_dmha_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_dmha_bwd": (c_int, [c_int] + [c_void_p] * 13 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "dasv_conv3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "dasv_conv3x3_packed_weight_bytes_x8": (c_size_t, [c_int, c_int]),
+    "dasv_conv3x3_pack_weights_x8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

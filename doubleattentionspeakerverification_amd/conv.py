@@ -17,8 +17,11 @@ __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights"
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu",
            "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
 
-MODES = {"split": 0, "bf16": 1, "fp16": 2}
-BACKWARD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16"}
+MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
+# "split8": fp32-grade forward on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8);
+# it needs fp16's exponent range on the operands, so gradients keep the split-bf16 kernel
+BACKWARD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split"}
+_PACK_KIND = {"split": 0, "bf16": 0, "fp16": 1, "split8": 2}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
 
 
@@ -46,20 +49,23 @@ class PackedConvWeights:
         self.owner = None
 
     def get(self, weight, mode="split"):
-        f16 = mode == "fp16"
+        kind = _PACK_KIND[mode]
         cacheable = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
-        key = (weight.data_ptr(), weight._version, weight.device, f16)
+        key = (weight.data_ptr(), weight._version, weight.device, kind)
         if not (cacheable and key == self.key and self.owner is not None and self.owner() is weight):
             lib = _lib.load()
             cout, cin = weight.shape[0], weight.shape[1]
             n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
+            nlo = max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cout, cin))   # the e4m3 plane carries its scale bytes behind it
             w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
             if self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
                 self.hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
-                self.lo = torch.empty(n, dtype=torch.uint8, device=weight.device)
+                self.lo = torch.empty(nlo, dtype=torch.uint8, device=weight.device)
             with torch.cuda.device(weight.device):
                 stream = torch.cuda.current_stream(weight.device).cuda_stream
-                if f16:
+                if kind == 2:
+                    rc = lib.dasv_conv3x3_pack_weights_x8(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)
+                elif kind == 1:
                     rc = lib.dasv_conv3x3_pack_weights_f16(w.data_ptr(), self.hi.data_ptr(), cout, cin, stream)
                 else:
                     rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)

@@ -15,6 +15,15 @@
 //   F16:  operands rounded to fp16 (11 mantissa bits, v_mfma_f32_16x16x32_f16), one MFMA per product; activations
 //     saturate at +-65504 and values below 6e-8 flush, so this is a forward/inference mode (weights come from
 //     dasv_conv3x3_pack_weights_f16).
+//   X8 (forward / inference mode of the fp32-grade path, window kernel only): v = hi + r with hi = fp16(v); the product is
+//     hi*hi on v_mfma_f32_16x16x32_f16 plus BOTH cross terms hi*r' + r*hi' on ONE block-scaled e4m3 MFMA per 64 channels
+//     (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 rate): the cross terms only need ~4 significant bits because r is
+//     already 2^-11 of v.  Operands of that MFMA: e4m3(v) and e4m3(r * 2^12) for activations (fixed exact power-of-two
+//     scale, undone by the instruction's E8M0 block scale), e4m3(w * 2^Sh[n]) and e4m3(r_w * 2^Sw[n]) for weights (scales
+//     per output channel, chosen when the weights are packed).  Pipe cycles per 64-channel tap: 2 x 16 + 32 = 64 instead of
+//     6 x 16 = 96 (tools/mfma_mix_probe.hip: 1.51x in a bare loop); measured error vs a float64 convolution ~1e-5 of the
+//     output scale for activations between 0.01 and 100 (split-bf16: 5e-6; plain fp16: 3e-4), degrading towards the fp16
+//     figure outside that range.  Needs fp16's exponent range on the hi part: activations, not gradients.
 // Tile: 128 pixels x 128 channels x 64 (one tap's channel slab) per 256-thread workgroup; 2x2 waves, each
 // 64x64 = 4x4 MFMA tiles.  Global -> registers (next K-step, issued before the MFMAs of the current one) ->
 // LDS (XOR-swizzled 16-byte slots so ds_read_b128 fragment reads spread over the banks) -> MFMA.
@@ -59,7 +68,8 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 }
 
 // precision of the MFMA operands: split-bf16 (three products), bf16, fp16
-constexpr int PREC_SPLIT = 0, PREC_BF16 = 1, PREC_F16 = 2;
+constexpr int PREC_SPLIT = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_X8 = 3;
+constexpr int X8_ACT_SHIFT = 12;   // activation residuals are stored as e4m3(r * 2^12)
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // staging conversion of two fp32 values: `hi` gets the packed 16-bit operands of the mode, `lo` the split residuals
@@ -79,6 +89,69 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     if (PREC == PREC_F16)
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// X8 staging of four fp32 values: fp16 hi (two words), e4m3 of the values, e4m3 of the scaled residuals.
+// v_cvt_pk_fp8_f32 rounds to nearest even and turns |v| >= 480 into NaN (checked: tools/fp8_mfma_check.hip): clamp first.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void cvt4_x8(f32x4 v, float rscale, uint32_t& h01, uint32_t& h23, uint32_t& v8, uint32_t& r8) {
+    float c[4], r[4];
+    _Float16 h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = __builtin_amdgcn_fmed3f(v[k], -65504.f, 65504.f);
+        h[k] = (_Float16)c[k];
+        r[k] = __builtin_amdgcn_fmed3f((c[k] - (float)h[k]) * rscale, -448.f, 448.f);
+        c[k] = __builtin_amdgcn_fmed3f(c[k], -448.f, 448.f);
+    }
+    const f16x2_t p0 = {h[0], h[1]}, p1 = {h[2], h[3]};
+    h01 = __builtin_bit_cast(uint32_t, p0);
+    h23 = __builtin_bit_cast(uint32_t, p1);
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    v8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], a, true);
+    int b = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
+    r8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], b, true);
+}
+
+// weights [Cout][Cin][3][3] fp32 (torch) -> X8 planes: fp16 [Cout][9][Cin] and, per (channel n, tap, 64-channel slab), 128
+// bytes { e4m3(r_w * 2^Sw[n]) x 64 | e4m3(w * 2^Sh[n]) x 64 }, then [Cout][4] scale bytes {127 - Sw, 127 - Sh, 0, 0} (the E8M0
+// block scales of the MFMA).  One workgroup per output channel: max |w| and max |r_w| first, then the planes.
+__global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const float* __restrict__ w, uint16_t* __restrict__ wh,
+                                                                       uint8_t* __restrict__ w8, int Cout, int Cin) {
+    __shared__ float red[2][4];
+    const int o = blockIdx.x, tid = threadIdx.x, n = 9 * Cin;
+    const float* wo = w + (size_t)o * n;
+    float mw = 0.f, mr = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float v = __builtin_amdgcn_fmed3f(wo[i], -65504.f, 65504.f);
+        mw = fmaxf(mw, fabsf(v));
+        mr = fmaxf(mr, fabsf(v - (float)(_Float16)v));
+    }
+    mw = group_max<64>(mw); mr = group_max<64>(mr);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = mw; red[1][tid >> 6] = mr; }
+    __syncthreads();
+    mw = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mr = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    // scale exponents: max * 2^S in (64, 128] (well inside e4m3's 448); 0 for an all-zero row / exactly representable weights
+    int eh = 0, el = 0;
+    if (mw > 0.f) { (void)frexpf(mw, &eh); eh = 7 - eh; }      // mw = f * 2^e, f in [0.5, 1)  ->  mw * 2^(7 - e) in [64, 128)
+    if (mr > 0.f) { (void)frexpf(mr, &el); el = 7 - el; }
+    eh = max(-100, min(100, eh)); el = max(-100, min(100, el));
+    const float sh = ldexpf(1.0f, eh), sl = ldexpf(1.0f, el);
+    uint8_t* sc = w8 + (size_t)Cout * n * 2;
+    if (tid == 0) { sc[o * 4 + 0] = (uint8_t)(127 - el); sc[o * 4 + 1] = (uint8_t)(127 - eh); sc[o * 4 + 2] = 0; sc[o * 4 + 3] = 0; }
+    const int nslab = Cin / 64;
+    for (int i = tid; i < n; i += 256) {
+        const int c = i % Cin, tap = i / Cin;          // destination order (tap, cin)
+        const float v = __builtin_amdgcn_fmed3f(wo[(size_t)c * 9 + tap], -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        wh[(size_t)o * n + i] = __builtin_bit_cast(uint16_t, h);
+        const float r = (v - (float)h) * sl;
+        const int c8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r, -448.f, 448.f), __builtin_amdgcn_fmed3f(v * sh, -448.f, 448.f), 0, false);
+        uint8_t* row = w8 + (((size_t)o * 9 + tap) * nslab + c / 64) * 128;
+        row[c % 64] = (uint8_t)(c8 & 0xff);
+        row[64 + c % 64] = (uint8_t)((c8 >> 8) & 0xff);
+    }
 }
 
 // weights [Cout][Cin][3][3] fp32 (torch) -> fp16 plane [Cout][9][Cin]
@@ -302,14 +375,17 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     static_assert(NWN == 2 || NWN == 4, "wave layout");
     static_assert(!C1 || NWN == 2, "the fused first layer stages with the 512-thread layout");
     constexpr int NT = 256 * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = (WMAXROWS * 16 + NT - 1) / NT, BCH = 1024 / NT;
+    constexpr bool X8 = PREC == PREC_X8;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
+    constexpr bool TWO = SPLIT || X8;      // two LDS planes per operand: bf16 hi | lo, or fp16 hi | the two e4m3 planes
+    static_assert(!X8 || (NWN == 2 && !C1), "the fp16 + e4m3 mode exists for the 8-wave layout, activations from memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int W = p.W, H = p.H, Cin = p.Cin;
     const int wrows = WBM + 2 * W + 2;
     char* Ahi = smem;
-    char* Alo = Ahi + (size_t)wrows * 128;
-    char* Bbase = Alo + (SPLIT ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
+    char* Alo = Ahi + (size_t)wrows * 128;   // X8: rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
+    char* Bbase = Alo + (TWO ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
 
     const int per_split = p.tiles_per_xcd * 8;
     const int ks = blockIdx.x / per_split, inner = blockIdx.x - ks * per_split;
@@ -345,32 +421,45 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         amask[i] = mask;
     }
 
-    // A window staging: chunk q = tid + NT*k covers window row q/16, fp32 chunk q%16 (4 channels)
+    // A window staging: chunk q = tid + NT*k covers window row q/16, fp32 chunk q%16 (4 channels).  NT is a multiple of 16, so a
+    // thread's chunks all sit in channel column tid & 15 and in rows (tid >> 4) + (NT/16) k: every global address is one running
+    // pointer + k * (NT/16) * Cin floats and every LDS address one base + k * (NT/16) * 128 bytes (row & 7, which the swizzle uses,
+    // does not change either).  Written that way on purpose: as independent expressions the compiler hoisted ~5 registers of
+    // addresses per chunk out of the slab loop (70 registers for 14 chunks) and spilled them once the tap loop needed more.
+    constexpr int RSTEP = NT / 16;
     const int wchunks = wrows * 16;
+    const int wach = tid & 15, wr0 = tid >> 4;
     const long long wbase = (long long)m0 - W - 1;   // global pixel index of window row 0
+    const long long pix0 = wbase + wr0;
+    const float* xrun = C1 ? nullptr : p.x + pix0 * Cin + wach * 4;   // advanced by 64 channels per slab; dereferenced only under `valid`
+    const size_t xstep = (size_t)RSTEP * Cin;
+    const int whi0 = lds_off(wr0, wach >> 1) + (wach & 1) * 8;
+    const int wl00 = lds_off(wr0, wach >> 2) + (wach & 3) * 4, wl10 = lds_off(wr0, 4 + (wach >> 2)) + (wach & 3) * 4;
     f32x4 ra[WACHN];
-    auto load_window = [&](int c0) {
+    auto load_window = [&](const float* xs) {
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
-            const int q = tid + NT * k;
-            const long long pix = wbase + (q >> 4);
+            const long long pix = pix0 + RSTEP * k;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < wchunks && pix >= 0 && pix < p.M) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)pix * Cin + c0 + (q & 15) * 4);
+            if (wr0 + RSTEP * k < wrows && pix >= 0 && pix < p.M) v = *reinterpret_cast<const f32x4*>(xs + k * xstep);
             ra[k] = v;
         }
     };
     auto store_window = [&]() {
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
-            const int q = tid + NT * k;
-            if (q < wchunks) {
-                const int row = q >> 4, ach = q & 15;
+            if (wr0 + RSTEP * k < wrows) {
                 uint32_t h0, l0, h1, l1;
-                cvt2<PREC>(ra[k][0], ra[k][1], h0, l0);
-                cvt2<PREC>(ra[k][2], ra[k][3], h1, l1);
-                const int o = lds_off(row, ach >> 1) + (ach & 1) * 8;
-                *reinterpret_cast<uint2*>(Ahi + o) = make_uint2(h0, h1);
-                if (SPLIT) *reinterpret_cast<uint2*>(Alo + o) = make_uint2(l0, l1);
+                if constexpr (X8) {
+                    cvt4_x8(ra[k], (float)(1 << X8_ACT_SHIFT), h0, h1, l0, l1);
+                    *reinterpret_cast<uint32_t*>(Alo + wl00 + k * (RSTEP * 128)) = l0;
+                    *reinterpret_cast<uint32_t*>(Alo + wl10 + k * (RSTEP * 128)) = l1;
+                } else {
+                    cvt2<PREC>(ra[k][0], ra[k][1], h0, l0);
+                    cvt2<PREC>(ra[k][2], ra[k][3], h1, l1);
+                    if (SPLIT) *reinterpret_cast<uint2*>(Alo + whi0 + k * (RSTEP * 128)) = make_uint2(l0, l1);
+                }
+                *reinterpret_cast<uint2*>(Ahi + whi0 + k * (RSTEP * 128)) = make_uint2(h0, h1);
             }
         }
     };
@@ -434,7 +523,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             const int q = tid + NT * k;
             const size_t off = ((size_t)(n0 + (q >> 3)) * 9 + tap) * Cin + c0 + (q & 7) * 8;
             rbh[k] = *reinterpret_cast<const u32x4*>(p.whi + off);
-            if (SPLIT) rbl[k] = *reinterpret_cast<const u32x4*>(p.wlo + off);
+            if (TWO) rbl[k] = *reinterpret_cast<const u32x4*>(p.wlo + off);   // X8: the 128-byte e4m3 rows have the same pitch
         }
     };
     auto store_b = [&](char* Bhi) {
@@ -443,9 +532,18 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             const int q = tid + NT * k;
             const int o = lds_off(q >> 3, q & 7);
             *reinterpret_cast<u32x4*>(Bhi + o) = rbh[k];
-            if (SPLIT) *reinterpret_cast<u32x4*>(Bhi + 16384 + o) = rbl[k];
+            if (TWO) *reinterpret_cast<u32x4*>(Bhi + 16384 + o) = rbl[k];
         }
     };
+    // X8: E8M0 block scales of the cross-term MFMA.  Block b of its K = 128 takes the scale byte of lane group b: blocks
+    // 0 / 2 pair e4m3(x) with the weight residuals, blocks 1 / 3 the activation residuals with e4m3(w) (tools/fp8_mfma_check.hip)
+    int wsc[JT];
+    const int xsc = (fq & 1) ? 127 - X8_ACT_SHIFT : 127;
+    if constexpr (X8) {
+        const uint8_t* sc = reinterpret_cast<const uint8_t*>(p.wlo) + (size_t)p.Cout * 9 * Cin * 2;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) wsc[j] = sc[(size_t)(n0 + wn * NPW + j * 16 + frow) * 4 + (fq & 1)];
+    }
 
     f32x4 acc[4][JT];
 #pragma unroll
@@ -457,9 +555,88 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
     load_b(0, sl_lo * CBK);
     int it = 0;
+    // PIPE (split-bf16, double-buffered tile, 8 waves, activations from memory): the fragments of a 32-channel half are read one
+    // half ahead of the MFMAs that use them, across taps: while half 0 of a tap is multiplied the fragments of half 1 arrive;
+    // while half 1 is multiplied the NEXT tap's first-half pixel fragments (same window) are read before the tap's barrier and its
+    // weight fragments (new tile) right after it.  The two waves of a SIMD run in step, so without this both read, then both
+    // multiply: two exposed read phases per tap.  tools/conv_core_probe.hip (same loop, LDS only): 2049 -> 1882 ns per tap.
+    // Needs 128 fragment registers: possible since the window staging addresses stopped occupying ~60 registers (above).
+    constexpr bool PIPE = SPLIT && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    if constexpr (PIPE) {
+        struct Frags { bf16x8 bh[JT], bl[JT], ah[4], al[4]; };
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int brow = wn * NPW + frow;
+        const int boff0 = lds_off(brow, fq), boff1 = lds_off(brow, 4 + fq);   // tiles are 16 rows = 2048 bytes apart
+        auto read_b = [&](Frags& f, const char* Bhi, int kk) {
+            const char* bp = Bhi + (kk ? boff1 : boff0);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                f.bh[j] = *reinterpret_cast<const bf16x8*>(bp + j * 2048);
+                f.bl[j] = *reinterpret_cast<const bf16x8*>(bp + 16384 + j * 2048);
+            }
+        };
+        auto read_a = [&](Frags& f, int tap, int kk) {
+            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            const int o = lds_off(arow, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (amask[i] >> tap) & 1u;
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(Ahi + o + i * 2048);
+                const bf16x8 l = *reinterpret_cast<const bf16x8*>(Alo + o + i * 2048);
+                f.ah[i] = ok ? h : zero;
+                f.al[i] = ok ? l : zero;
+            }
+        };
+        auto mma_rows = [&](const Frags& f, int i0, int i1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < i0 || i >= i1) continue;
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        Frags fa, fb;
+        for (int sl = sl_lo; sl < nslab; ++sl) {
+            const int c0 = sl * CBK;
+            load_window(xrun + c0);
+            if (sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
+            store_window();
+            {   // first tap of the slab: its tile is in registers (fetched during the previous tap / before the loop)
+                char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                store_b(Bcur);
+                __syncthreads();
+                load_b(1, c0);
+                read_b(fa, Bcur, 0);
+                read_a(fa, 0, 0);
+            }
+            for (int tap = 0; tap < 9; ++tap, ++it) {
+                char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
+                read_b(fb, Bcur, 1);
+                read_a(fb, tap, 1);
+                mma_rows(fa, 0, 4);
+                if (tap < 8) {
+                    store_b(Bnxt);             // the next tap's tile: that buffer was last read before the previous barrier
+                    read_a(fa, tap + 1, 0);    // same window: no need to wait for the barrier
+                }
+                mma_rows(fb, 0, 2);
+                if (tap < 8) {
+                    __syncthreads();
+                    if (tap < 7) load_b(tap + 2, c0);
+                    else if (sl + 1 < nslab) load_b(0, c0 + CBK);
+                    read_b(fa, Bnxt, 0);
+                }
+                mma_rows(fb, 2, 4);
+            }
+        }
+    } else
     for (int sl = sl_lo; sl < nslab; ++sl) {
         const int c0 = sl * CBK;
-        if (!C1 && (DASV_CONV_DIAG != 1 || sl == sl_lo)) load_window(c0);
+        if (!C1 && (DASV_CONV_DIAG != 1 || sl == sl_lo)) load_window(xrun + c0);
         if (DBUF && sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
         if (C1) stage_window_c1(c0);
         else if (DASV_CONV_DIAG != 1 || sl == sl_lo) store_window();
@@ -485,8 +662,85 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             // 248 registers, no spills): 3-5 % SLOWER on every double-buffered layer with the phases fenced or left to the
             // scheduler, 6-10 % slower with reads-first hints — the matrix pipe is not waiting for fragment reads here.
             const int shift = (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            if constexpr (X8) {
+                // The fragment reads of the tap go out ahead of the MFMAs that use them, in consumption order: both fp16 halves and
+                // the weight e4m3 fragments first (24 ds_read_b128, 96 registers), the pixel e4m3 fragments into the registers the
+                // first half's MFMAs have freed.  Only the first group's LDS latency is exposed.  With a read phase in front of each
+                // of the three MFMA groups the two waves of a SIMD, which run in step, left the matrix pipe idle three times per
+                // tap (1.91 us per tap against 2.09 for split-bf16: the saved pipe cycles were lost again).
+                // Addresses: tiles are 16 rows apart and the swizzle uses row & 7, so every fragment is base(operand, slot) + a
+                // compile-time tile * 2048.
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                const u32x4 z4 = {0u, 0u, 0u, 0u};
+                const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
+                const int brow = wn * NPW + frow, arow = wm * 64 + frow + shift;
+                const char* bp0 = Bhi + lds_off(brow, fq);
+                const char* bp1 = Bhi + lds_off(brow, 4 + fq);
+                const char* bq0 = Bhi + 16384 + lds_off(brow, s1);
+                const char* bq1 = Bhi + 16384 + lds_off(brow, s2);
+                const char* ap0 = Ahi + lds_off(arow, fq);
+                const char* ap1 = Ahi + lds_off(arow, 4 + fq);
+                const char* aq0 = Alo + lds_off(arow, s1);
+                const char* aq1 = Alo + lds_off(arow, s2);
+                bf16x8 bh0[JT], bh1[JT], ah0[4], ah1[4];
+                u32x4 wl[JT], wh[JT], xl[4], xh[4];
 #pragma unroll
-            for (int kk = 0; kk < (DASV_CONV_DIAG == 2 ? 0 : 2); ++kk) {
+                for (int j = 0; j < JT; ++j) bh0[j] = *reinterpret_cast<const bf16x8*>(bp0 + j * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ah0[i] = *reinterpret_cast<const bf16x8*>(ap0 + i * 2048);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) bh1[j] = *reinterpret_cast<const bf16x8*>(bp1 + j * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ah1[i] = *reinterpret_cast<const bf16x8*>(ap1 + i * 2048);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    wl[j] = *reinterpret_cast<const u32x4*>(bq0 + j * 2048);
+                    wh[j] = *reinterpret_cast<const u32x4*>(bq1 + j * 2048);
+                }
+                // hi * hi, first 32-channel half
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 a = ((amask[i] >> tap) & 1u) ? ah0[i] : zero;
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh0[j], a, acc[i][j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xl[i] = *reinterpret_cast<const u32x4*>(aq0 + i * 2048);
+                    xh[i] = *reinterpret_cast<const u32x4*>(aq1 + i * 2048);
+                }
+                // hi * hi, second half
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 a = ((amask[i] >> tap) & 1u) ? ah1[i] : zero;
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh1[j], a, acc[i][j]);
+                }
+                // both cross terms of both halves: one K = 128 block-scaled e4m3 MFMA per tile.  A lane's eight operand registers are
+                // 16 bytes of block fq >> 1 (channels 16 (fq & 1) ...) and 16 bytes of block 2 + (fq >> 1) (channels 32 + 16 (fq & 1) ...)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (amask[i] >> tap) & 1u;
+                    const u32x4 lo = ok ? xl[i] : z4, hi = ok ? xh[i] : z4;
+                    const i32x8 x8 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) {
+                        const i32x8 w8 = {(int)wl[j][0], (int)wl[j][1], (int)wl[j][2], (int)wl[j][3], (int)wh[j][0], (int)wh[j][1], (int)wh[j][2], (int)wh[j][3]};
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, x8, acc[i][j], 0, 0, 0, wsc[j], 0, xsc);
+                    }
+                }
+                // reads -> MFMA groups in source order: 24 reads | 4 selects + 16 MFMAs | 8 reads | 4 + 16 | 8 selects + 16
+                __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < ((DASV_CONV_DIAG == 2 || X8) ? 0 : 2); ++kk) {
                 const int slot = kk * 4 + fq;
                 bf16x8 bh[JT], bl[JT];
 #pragma unroll
@@ -638,6 +892,19 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
     return (int)hipGetLastError();
 }
 
+size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)Cout * 9 * Cin * sizeof(uint16_t) + (size_t)Cout * 4;   // the e4m3 plane carries [Cout][4] scale bytes behind it
+}
+
+int dasv_conv3x3_pack_weights_x8(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
+    if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
+    if (Cout <= 0 || Cin <= 0 || Cin % 64 != 0) return DASV_E_SHAPE;
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin);
+    return (int)hipGetLastError();
+}
+
 int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream) {
     if (w == nullptr || w_f16 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0) return DASV_E_SHAPE;
@@ -652,12 +919,13 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
                           const int* row_span = nullptr) {
-    if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || (mode == 0 && w_lo == nullptr)) return DASV_E_NULL;
+    if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return DASV_E_SHAPE;
     if ((long long)B * H * W > 0x7fffffffLL / 2) return DASV_E_SHAPE;
-    if (mode < 0 || mode > 2) return DASV_E_DTYPE;
+    if (mode < 0 || mode > 3) return DASV_E_DTYPE;
+    if (mode == 3 && (W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // fp16 + e4m3 mode: window kernel, activations from memory
     dasv::ConvParams p;
     p.x = x; p.whi = static_cast<const uint16_t*>(w_hi); p.wlo = static_cast<const uint16_t*>(w_lo); p.bias = bias; p.mask = mask; p.colsum = colsum; p.y = y;
     if (colsum != nullptr && W > 80) return DASV_E_SHAPE;   // only the window kernel carries the column sums
@@ -673,8 +941,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
-        const size_t lds1 = (size_t)wrows * 128 * (mode == 0 ? 2 : 1) + 32768;
-        const bool dbuf = mode == 0 && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
+        const size_t lds1 = (size_t)wrows * 128 * ((mode == 0 || mode == 3) ? 2 : 1) + 32768;
+        const bool dbuf = (mode == 0 || mode == 3) && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
         const size_t lds = lds1 + (dbuf ? 32768 : 0);
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
         const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
@@ -699,7 +967,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true, 2);
             else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true, 2);
             else DASV_LAUNCH_WINDOW(2, false, true, 2);
-        } else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false, 2);
+        } else if (mode == 3 && dbuf) DASV_LAUNCH_WINDOW(3, true, false, 2);
+        else if (mode == 3) DASV_LAUNCH_WINDOW(3, false, false, 2);
+        else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false, 2);
         else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false, 4);
         else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false, 2);
         else DASV_LAUNCH_WINDOW(2, false, false, 2);

@@ -144,6 +144,14 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
 size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin);
 int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
+/*       mode 3: fp32-grade on fewer matrix-pipe cycles, FORWARD / activations only, maps up to 80 columns: v = hi + r with
+ *               hi = fp16(v); hi*hi on the fp16 MFMA, both cross terms hi*r' + r*hi' on one block-scaled e4m3 MFMA per 64
+ *               input channels (residuals are 2^-11 of the value, 4 significant bits suffice).  ~1e-5 of the output scale
+ *               against a float64 convolution for activations between 0.01 and 100 (mode 0: 5e-6, mode 2: 3e-4).  w_hi =
+ *               the fp16 plane and w_lo = the e4m3 plane (+ per-channel scale bytes) of dasv_conv3x3_pack_weights_x8;
+ *               w_lo holds dasv_conv3x3_packed_weight_bytes_x8(Cout, Cin) bytes.  Gradients go through mode 0. */
+size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin);
+int dasv_conv3x3_pack_weights_x8(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 /* Same with a caller-provided workspace of dasv_conv3x3_workspace_bytes() bytes: when the map has too few output tiles to
