@@ -11,7 +11,9 @@ checkpoints load with strict=True.
 Convolutions: the wide layers (Cin % 64 == 0, Cout % 128 == 0 — everything but conv11 at the reference's
 kernel sizes) run on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU` of csrc/conv3x3.hip on fp32
 NHWC activations; `conv_mode`:
-  "split"  (default) fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product)
+  "split8" (default) fp32-grade forward: fp16 products + block-scaled e4m3 cross terms (~1e-5 of the output scale per layer);
+           the backward pass of these layers runs in "split"
+  "split"  fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product, ~5e-6)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
   "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs for narrow layers)
@@ -59,7 +61,7 @@ class _VGG(nn.Module):
             setattr(self, "conv%d2" % blk, nn.Conv2d(cout, cout, 3, stride=1, padding=1))
             cin = cout
         self.channels_last = True
-        self.conv_mode = "split"
+        self.conv_mode = "split8"
         # conv11 fused into conv12's window staging (one launch, conv11's 786 MB output never reaches HBM): correct and
         # tested, but measured SLOWER end to end (6.74 vs 6.63 ms per [64,300,80] batch): conv12's loop is issue-bound and
         # the nine extra FMAs per staged value cost more than the saved traffic.  Off by default.
@@ -122,7 +124,8 @@ class _VGG(nn.Module):
                 if packed is None:
                     packed = self._packed[key] = _hipconv.PackedConvWeights()
                 h = _hipconv.conv3x3_c1_conv3x3_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias,
-                                                          c12.weight, c12.bias, packed, self._mode())
+                                                          c12.weight, c12.bias, packed,
+                                                          "split" if self._mode() == "split8" else self._mode())   # no fused form of split8
             elif grad:
                 h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias)
             else:

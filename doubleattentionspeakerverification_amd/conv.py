@@ -1,10 +1,13 @@
 """conv3x3 + bias + ReLU through libdasv_hip.so (csrc/conv3x3.hip): the hand-written MFMA implicit-GEMM that
 replaces `F.relu(self.convXY(x))` of the reference's CNNs.py:38-48 / 72-86 for the wide layers.
 
-Activations stay fp32 in NHWC memory (torch `channels_last` tensors are passed zero-copy).  mode "split" keeps fp32
-accuracy on the bf16 matrix cores (operands split hi + lo, three MFMAs per product); mode "bf16" rounds operands to
-bf16, mode "fp16" to fp16 (11 mantissa bits, forward only: its gradients run with bf16 operands, whose exponent range
-covers small gradients).  Backward: data gradient = the same kernel with transposed, flipped weights; weight gradient =
+Activations stay fp32 in NHWC memory (torch `channels_last` tensors are passed zero-copy).  Operand precision (`mode`):
+  "split8"  fp32-grade forward on the fewest matrix-pipe cycles: v = fp16 hi + residual, hi*hi on the fp16 MFMA, both cross terms
+            on one block-scaled e4m3 MFMA (~1e-5 of the output scale vs a float64 convolution); activations only — gradients
+            of a layer run in "split";
+  "split"   fp32-grade on the bf16 matrix cores, forward and backward (operands split hi + lo, three MFMAs per product, ~5e-6);
+  "bf16"    operands rounded to bf16;  "fp16"  operands rounded to fp16 (11 mantissa bits, forward only: its gradients run with
+            bf16 operands, whose exponent range covers small gradients).  Backward: data gradient = the same kernel with transposed, flipped weights; weight gradient =
 csrc/conv3x3_wgrad.hip.
 """
 import weakref
@@ -212,6 +215,8 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         raise RuntimeError("unsupported conv3x3 shape/dtype for the HIP kernel: %s %s" % (tuple(weight.shape), x.dtype))
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
+    if mode == "split8" and x.shape[3] > 80:
+        mode = "split"   # the fp16 + e4m3 form exists in the window kernel (maps up to 80 columns) only
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
     return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out)

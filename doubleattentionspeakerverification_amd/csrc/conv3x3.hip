@@ -633,6 +633,103 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 mma_rows(fb, 2, 4);
             }
         }
+    } else if constexpr (X8 && DBUF && NWN == 2 && DASV_CONV_DIAG == 0) {
+        // The same software pipeline for the fp16 + e4m3 mode.  Per tap three MFMA groups: fp16 half 0, fp16 half 1 (16 MFMAs of 16
+        // cycles each), e4m3 cross terms (16 MFMAs of 32 cycles).  The fragments of fp16 half 1 and the e4m3 fragments are read at
+        // the top of the tap, while half 0 (fetched during the previous tap) is multiplied; the NEXT tap's half-0 fragments while
+        // the e4m3 group runs — pixel part before the tap's barrier, weight part after it.  (Carrying both fp16 halves across the
+        // barrier needs 32 more registers than there are: spill reloads inside the tap loop, 3 % slower than no pipeline.)
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
+        const int brow = wn * NPW + frow;
+        const int bo0 = lds_off(brow, fq), bo1 = lds_off(brow, 4 + fq);
+        const int bq0 = 16384 + lds_off(brow, s1), bq1 = 16384 + lds_off(brow, s2);
+        bf16x8 bh0[JT], bh1[JT], ah0[4], ah1[4];
+        u32x4 wl[JT], wh[JT], xl[4], xh[4];
+        auto read_f16_b = [&](bf16x8 (&bh)[JT], const char* Bhi, int kk) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (kk ? bo1 : bo0) + j * 2048);
+        };
+        auto read_f16_a = [&](bf16x8 (&ah)[4], int tap, int kk) {
+            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            const int o = lds_off(arow, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ahi + o + i * 2048);
+                ah[i] = ((amask[i] >> tap) & 1u) ? v : zero;
+            }
+        };
+        auto read_e4m3 = [&](const char* Bhi, int tap) {
+            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            const int o0 = lds_off(arow, s1), o1 = lds_off(arow, s2);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                wl[j] = *reinterpret_cast<const u32x4*>(Bhi + bq0 + j * 2048);
+                wh[j] = *reinterpret_cast<const u32x4*>(Bhi + bq1 + j * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (amask[i] >> tap) & 1u;
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(Alo + o0 + i * 2048);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(Alo + o1 + i * 2048);
+                xl[i] = ok ? lo : z4;
+                xh[i] = ok ? hi : z4;
+            }
+        };
+        auto mma_f16 = [&](const bf16x8 (&b)[JT], const bf16x8 (&a)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(b[j], a[i], acc[i][j]);
+        };
+        auto mma_e4m3 = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < i0 || i >= i1) continue;
+                const i32x8 x8 = {(int)xl[i][0], (int)xl[i][1], (int)xl[i][2], (int)xl[i][3], (int)xh[i][0], (int)xh[i][1], (int)xh[i][2], (int)xh[i][3]};
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const i32x8 w8 = {(int)wl[j][0], (int)wl[j][1], (int)wl[j][2], (int)wl[j][3], (int)wh[j][0], (int)wh[j][1], (int)wh[j][2], (int)wh[j][3]};
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, x8, acc[i][j], 0, 0, 0, wsc[j], 0, xsc);
+                }
+            }
+        };
+        for (int sl = sl_lo; sl < nslab; ++sl) {
+            const int c0 = sl * CBK;
+            load_window(xrun + c0);
+            if (sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
+            store_window();
+            {
+                char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                store_b(Bcur);
+                __syncthreads();
+                load_b(1, c0);
+                read_f16_b(bh0, Bcur, 0);
+                read_f16_a(ah0, 0, 0);
+            }
+            for (int tap = 0; tap < 9; ++tap, ++it) {
+                char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
+                read_f16_b(bh1, Bcur, 1);
+                read_f16_a(ah1, tap, 1);
+                read_e4m3(Bcur, tap);
+                mma_f16(bh0, ah0);
+                mma_f16(bh1, ah1);
+                if (tap < 8) {
+                    store_b(Bnxt);
+                    read_f16_a(ah0, tap + 1, 0);
+                }
+                mma_e4m3(0, 2);
+                if (tap < 8) {
+                    __syncthreads();
+                    if (tap < 7) load_b(tap + 2, c0);
+                    else if (sl + 1 < nslab) load_b(0, c0 + CBK);
+                    read_f16_b(bh0, Bnxt, 0);
+                }
+                mma_e4m3(2, 4);
+            }
+        }
     } else
     for (int sl = sl_lo; sl < nslab; ++sl) {
         const int c0 = sl * CBK;

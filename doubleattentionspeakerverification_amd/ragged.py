@@ -82,7 +82,7 @@ def front_end_ragged(front, utterances, mode=None):
         raise RuntimeError("the ragged front-end runs on the GPU only (libdasv_hip.so); no CPU fallback")
     mode = mode or front.conv_mode
     if mode == "torch":
-        raise RuntimeError("the ragged path needs the HIP convolutions (conv_mode split / bf16 / fp16)")
+        raise RuntimeError("the ragged path needs the HIP convolutions (conv_mode split8 / split / bf16 / fp16)")
     x = torch.cat([u.to(dev, torch.float32) for u in utterances], dim=0).contiguous()        # [rows, 80]
     W = x.shape[1]
     spans, pools, lens = ragged_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev)

@@ -216,10 +216,13 @@ def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
     scale = float(ref.abs().max())
     with torch.no_grad():
         ys = conv.conv3x3_bias_relu(x, w, b, None, "split").cpu().double()
+        y8 = conv.conv3x3_bias_relu(x, w, b, None, "split8").cpu().double()
         yb = conv.conv3x3_bias_relu(x, w, b, None, "bf16").cpu().double()
         yh = conv.conv3x3_bias_relu(x, w, b, None, "fp16").cpu().double()
     assert ys.shape == ref.shape
     assert float((ys - ref).abs().max()) / scale < 2e-5
+    # fp16 products + block-scaled e4m3 cross terms: fp32-grade too (emulated and measured ~1e-5; plain fp16 is ~3e-4)
+    assert y8.shape == ref.shape and float((y8 - ref).abs().max()) / scale < 4e-5
     assert float((yb - ref).abs().max()) / scale < 1e-2
     assert float((yh - ref).abs().max()) / scale < 1.25e-3   # fp16 operands: 8x tighter than bf16
     if cin == 64:   # fp16 mode saturates instead of overflowing: a 1e6 activation gives a finite map
@@ -227,6 +230,30 @@ def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
         xb[0, 0, 0, 0] = 1e6
         with torch.no_grad():
             assert torch.isfinite(conv.conv3x3_bias_relu(xb, w, b, None, "fp16")).all()
+            assert torch.isfinite(conv.conv3x3_bias_relu(xb, w, b, None, "split8")).all()   # e4m3 operands are clamped, not NaN
+
+
+def test_split8_mode_accuracy_over_activation_scales_and_wide_map_fallback():
+    """The fp16 + e4m3 mode keeps fp32-grade accuracy for activations between 0.01 and 100 (fixed 2^12 residual scale) and
+    degrades towards the plain-fp16 figure, never beyond, outside; maps wider than 80 columns run in split mode."""
+    from doubleattentionspeakerverification_amd import conv
+    cin, cout, H, W, B = 256, 128, 12, 20, 2
+    w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    x0 = torch.relu(torch.from_numpy(rnd(1, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
+    errs = {}
+    for sx in (1e-3, 1e-2, 1.0, 30.0, 100.0, 1e3):
+        x = (x0 * sx).contiguous(memory_format=torch.channels_last)
+        ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+        with torch.no_grad():
+            y = conv._launch(x, *conv.PackedConvWeights().get(w, "split8"), None, cout, "split8", relu=0).cpu().double()
+        errs[sx] = float((y - ref).abs().max() / ref.abs().max())
+    print("split8 error vs activation scale:", errs)
+    assert max(errs[1e-2], errs[1.0], errs[30.0], errs[100.0]) < 4e-5
+    assert max(errs.values()) < 6e-4
+    xw = torch.from_numpy(rnd(4, 1, 64, 3, 96)).to(DEV).contiguous(memory_format=torch.channels_last)
+    ww = torch.from_numpy(rnd(5, 128, 64, 3, 3, scale=0.05)).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(conv.conv3x3_bias_relu(xw, ww, None, None, "split8"), conv.conv3x3_bias_relu(xw, ww, None, None, "split"))
 
 
 def test_hip_conv_backward_matches_torch_autograd():
