@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace summaries and PMC traffic passes for bench.py.
 # Raw CSVs land under gpurun_out/prof_$TAG/; tools/summarize_profiles.py turns them into profiles/$TAG_*.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

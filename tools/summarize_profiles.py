@@ -52,7 +52,7 @@ traffic, md = {}, ["# rocprofv3 summary, round tag `%s`\n\n" % tag,
                    "`--pmc WRITE_SIZE` passes) around `python3 bench.py --workload pool ...` and `python3 bench.py ...`.\n\n" % tag,
                    "FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads, MI355X_MICROARCH.md "
                    "section HBM); both counters are KiB.\n"]
-alg = {"pool": 39954688, "embed": 24965760}
+alg = {"pool": 39954688, "embed": 24965760}   # embed: the in-model [64,19,5120] launch (alignments not materialised)
 for run in ("pool", "embed"):
     st = stats(run)
     fe, wr = pmc(run, "FETCH_SIZE"), pmc(run, "WRITE_SIZE")
@@ -72,48 +72,47 @@ for run in ("pool", "embed"):
     if run == "embed":
         rows = list(csv.DictReader(open(one("embed_trace/*/*kernel_stats.csv"))))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        # passes in the run: warm-up 2 + timed 6 + 1 reference pass in fp32-grade (split) mode, then the same 9 in the
-        # fp16-operand companion mode (bench.py's `reduced_precision_fp16_operands`); conv kernels carry the mode in their
-        # first template argument (0 = split, 2 = fp16), the other kernels are shared by both.
-        split = [r for r in rows if "conv3x3_window_kernel<0" in r["Name"]]
-        half = [r for r in rows if "conv3x3_window_kernel<2" in r["Name"]]
-        passes = sum(int(r["Calls"]) for r in split) / 7.0
-        passes16 = sum(int(r["Calls"]) for r in half) / 7.0
-        md.append("* passes in this run: %d fp32-grade (split-bf16 conv operands) + %d fp16-operand companion passes\n" % (passes, passes16))
+        # The run holds the headline passes (conv operand mode split8: conv3x3_window_kernel<3,..>) and bench.py's companion
+        # passes in the other operand modes (`conv_operand_modes`: <0,..> = split-bf16, <2,..> = fp16); the other kernels are shared.
+        names = {"3": "split8 (fp16 products + block-scaled e4m3 cross terms; the headline)", "0": "split-bf16 (companion)",
+                 "2": "fp16 operands (companion)"}
+        pipe = {"3": 2, "0": 3, "2": 1}      # matrix-pipe time per algorithmic FLOP in units of a plain bf16 MFMA
         md.append("* kernel mix of the whole run (all GPU kernels, %.2f ms of kernel time):\n" % (tot / 1e6))
-        for r in rows[:9]:
+        for r in rows[:10]:
             md.append("  * `%s` — %s calls, avg %.1f us, %.1f %% of kernel time\n"
                       % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
         flops = 64 * (39.13e9 - 0.055e9)   # seven wide layers of VGG4L/1024 at T=300 (SURVEY appendix D.1 minus conv11)
-        if split:
-            per_step = sum(float(c["TotalDurationNs"]) for c in split) / passes / 1e3
-            md.append("* `conv3x3_window_kernel<0,..>` (split mode, the headline): %.0f us per step over 7 launches -> %.0f TFLOP/s "
-                      "algorithmic (x3 executed on the MFMA pipe = %.0f TFLOP/s, %.0f %% of the 2.5 PFLOP/s dense bf16 peak)\n"
-                      % (per_step, flops / per_step / 1e6, 3 * flops / per_step / 1e6, 100 * 3 * flops / per_step / 1e6 / 2500))
-        if half:
-            per_step = sum(float(c["TotalDurationNs"]) for c in half) / passes16 / 1e3
-            md.append("* `conv3x3_window_kernel<2,..>` (fp16 operands, companion): %.0f us per step -> %.0f TFLOP/s (%.0f %% of peak)\n"
-                      % (per_step, flops / per_step / 1e6, 100 * flops / per_step / 1e6 / 2500))
-        # HBM traffic of the split-mode conv launches (separate PMC passes; same gfx950 doubling of FETCH_SIZE)
-        def conv_pmc(which, counter):
+        for code in ("3", "0", "2"):
+            ks = [r for r in rows if "conv3x3_window_kernel<%s," % code in r["Name"]]
+            if not ks:
+                continue
+            calls = sum(int(r["Calls"]) for r in ks)
+            per_step = sum(float(c["TotalDurationNs"]) for c in ks) / (calls / 7.0) / 1e3
+            md.append("* `conv3x3_window_kernel<%s,..>` %s: %d launches, %.0f us per step over the 7 layers (average launch %.1f us) -> %.0f "
+                      "TFLOP/s algorithmic = %.1f %% of the 2.5 PFLOP/s dense bf16 peak; matrix-pipe time x%d -> %.0f %% of the pipe\n"
+                      % (code, names[code], calls, per_step, per_step / 7, flops / per_step / 1e6, 100 * flops / per_step / 1e6 / 2500,
+                         pipe[code], 100 * pipe[code] * flops / per_step / 1e6 / 2500))
+        # HBM traffic of the conv launches per operand mode (separate PMC passes; same gfx950 doubling of FETCH_SIZE)
+        def conv_pmc(which, counter, code):
             path = one("embed_%s/*/*counter_collection.csv" % which)
             v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                 if "conv3x3_window_kernel<0" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                 if "conv3x3_window_kernel<%s," % code in r["Kernel_Name"] and r["Counter_Name"] == counter]
             return sum(v) / len(v) if v else float("nan")
-        cf, cw = conv_pmc("fetch", "FETCH_SIZE") * 1024 * 2, conv_pmc("write", "WRITE_SIZE") * 1024
-        # algorithmic bytes of an average launch: read x, write y (fp32 NHWC), read both bf16 weight planes once
         layers = [(128, 128, 300, 80), (128, 256, 150, 40), (256, 256, 150, 40), (256, 512, 75, 20), (512, 512, 75, 20),
                   (512, 1024, 38, 10), (1024, 1024, 38, 10)]
+        # algorithmic bytes of an average launch: read x, write y (fp32 NHWC), read both 16-bit weight planes once
         calg = sum(64 * h * w * (ci + co) * 4 + 2 * 2 * 9 * ci * co for ci, co, h, w in layers) / len(layers)
-        if cf == cf and cw == cw:
-            traffic["embed_conv_split"] = {"kernel": "dasv::conv3x3_window_kernel<0,..>", "fetch_bytes_x2": cf, "write_bytes": cw,
-                                           "hbm_bytes_per_launch": int(cf + cw), "algorithmic_bytes_per_launch": int(calg)}
-            md.append("* conv PMC per launch (average over the seven layers): FETCH_SIZE x2 = %.1f MB, WRITE_SIZE = %.1f MB -> HBM "
-                      "traffic %.1f MB vs %.1f MB algorithmic (x + y + both weight planes once): x%.2f.  Writes are exact.  The counters "
-                      "sit on the L2's fabric side and include Infinity-Cache hits (MI355X_MICROARCH.md): the excess reads are the "
-                      "weight planes (up to 37.7 MB for conv42, resident in the 256 MiB Infinity Cache) streamed once per XCD and "
-                      "per round of workgroups, plus the window halo.  At ~1 TB/s average the kernel stays MFMA-bound\n"
-                      % (cf / 1e6, cw / 1e6, (cf + cw) / 1e6, calg / 1e6, (cf + cw) / calg))
+        for code, key in (("3", "split8"), ("0", "split")):
+            cf, cw = conv_pmc("fetch", "FETCH_SIZE", code) * 1024 * 2, conv_pmc("write", "WRITE_SIZE", code) * 1024
+            if cf == cf and cw == cw:
+                traffic["embed_conv_%s" % key] = {"kernel": "dasv::conv3x3_window_kernel<%s,..>" % code, "fetch_bytes_x2": cf, "write_bytes": cw,
+                                                  "hbm_bytes_per_launch": int(cf + cw), "algorithmic_bytes_per_launch": int(calg)}
+                md.append("* conv PMC per launch, mode %s (average over the seven layers): FETCH_SIZE x2 = %.1f MB, WRITE_SIZE = %.1f MB -> HBM "
+                          "traffic %.1f MB vs %.1f MB algorithmic (x + y + both weight planes once): x%.2f.  Writes are exact.  The counters "
+                          "sit on the L2's fabric side and include Infinity-Cache hits (MI355X_MICROARCH.md): the excess reads are the "
+                          "weight planes (up to 37.7 MB for conv42, resident in the 256 MiB Infinity Cache) streamed once per XCD and "
+                          "per round of workgroups, plus the window halo.  The kernel stays MFMA-bound\n"
+                          % (key, cf / 1e6, cw / 1e6, (cf + cw) / 1e6, calg / 1e6, (cf + cw) / calg))
     if bl:
         pr = bl.get("roofline_pooling") or bl["roofline"]
         md.append("* bench.py under the profiler: value %.1f %s; pooling-kernel avg_launch_us %.2f by events (includes the event/launch gap)\n"
