@@ -386,6 +386,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     char* Ahi = smem;
     char* Alo = Ahi + (size_t)wrows * 128;   // X8: rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
     char* Bbase = Alo + (TWO ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
+    // 128 zero bytes behind the tile buffers (pipelined loops): a border tap reads its fragment from here — ONE address select per
+    // fragment instead of a data select per fragment register (probe: the selects cost 45 ns of a 1.9 us tap)
+    char* Zrow = Bbase + (DBUF ? 65536 : 32768);
+    if (DBUF && TWO && NWN == 2 && !C1 && threadIdx.x < 8)
+        *reinterpret_cast<u32x4*>(Zrow + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};   // visible after the first barrier of the loop
 
     const int per_split = p.tiles_per_xcd * 8;
     const int ks = blockIdx.x / per_split, inner = blockIdx.x - ks * per_split;
@@ -535,6 +540,24 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             if (TWO) *reinterpret_cast<u32x4*>(Bhi + 16384 + o) = rbl[k];
         }
     };
+    // Pipelined loops: the weight tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write; the
+    // probe put the tile stores at 75 ns of a tap).  A wave-instruction writes 1 KB = 8 rows x 8 physical slots in lane order, so
+    // the XOR swizzle moves to the SOURCE: lane L lands at (row L >> 3, slot L & 7) and fetches logical chunk (L & 7) ^ (L >> 3).
+    // Wave w moves pieces 2w, 2w+1 of both planes (rows 16w ... 16w+15).  The DMA is counted in vmcnt: the __syncthreads() in
+    // front of the barrier after which the tile is read drains it.
+    auto dma_b = [&](char* Bdst, int tap, int c0) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+        const int wu = __builtin_amdgcn_readfirstlane(wv);
+        const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wu * 2 + k;
+            const size_t off = ((size_t)(n0 + piece * 8 + lrow) * 9 + tap) * Cin + c0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.whi + off), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
+        }
+    };
     // X8: E8M0 block scales of the cross-term MFMA.  Block b of its K = 128 takes the scale byte of lane group b: blocks
     // 0 / 2 pair e4m3(x) with the weight residuals, blocks 1 / 3 the activation residuals with e4m3(w) (tools/fp8_mfma_check.hip)
     int wsc[JT];
@@ -553,7 +576,9 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 
     // split-K: this workgroup covers channel slabs [sl_lo, nslab) of the Cin / 64
     const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
-    load_b(0, sl_lo * CBK);
+    constexpr bool PIPELINED = TWO && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    if constexpr (PIPELINED) dma_b(Bbase, 0, sl_lo * CBK);
+    else load_b(0, sl_lo * CBK);
     int it = 0;
     // PIPE (split-bf16, double-buffered tile, 8 waves, activations from memory): the fragments of a 32-channel half are read one
     // half ahead of the MFMAs that use them, across taps: while half 0 of a tap is multiplied the fragments of half 1 arrive;
@@ -564,7 +589,6 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     constexpr bool PIPE = SPLIT && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPE) {
         struct Frags { bf16x8 bh[JT], bl[JT], ah[4], al[4]; };
-        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         const int brow = wn * NPW + frow;
         const int boff0 = lds_off(brow, fq), boff1 = lds_off(brow, 4 + fq);   // tiles are 16 rows = 2048 bytes apart
         auto read_b = [&](Frags& f, const char* Bhi, int kk) {
@@ -581,10 +605,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
-                const bf16x8 h = *reinterpret_cast<const bf16x8*>(Ahi + o + i * 2048);
-                const bf16x8 l = *reinterpret_cast<const bf16x8*>(Alo + o + i * 2048);
-                f.ah[i] = ok ? h : zero;
-                f.al[i] = ok ? l : zero;
+                f.ah[i] = *reinterpret_cast<const bf16x8*>(ok ? Ahi + o + i * 2048 : Zrow);
+                f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * 2048 : Zrow);
             }
         };
         auto mma_rows = [&](const Frags& f, int i0, int i1) {
@@ -605,11 +627,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             load_window(xrun + c0);
             if (sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
             store_window();
-            {   // first tap of the slab: its tile is in registers (fetched during the previous tap / before the loop)
+            {   // first tap of the slab: its tile is on its way by DMA (issued during the previous slab / before the loop)
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
-                store_b(Bcur);
                 __syncthreads();
-                load_b(1, c0);
+                dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_b(fa, Bcur, 0);
                 read_a(fa, 0, 0);
             }
@@ -619,15 +640,13 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 read_b(fb, Bcur, 1);
                 read_a(fb, tap, 1);
                 mma_rows(fa, 0, 4);
-                if (tap < 8) {
-                    store_b(Bnxt);             // the next tap's tile: that buffer was last read before the previous barrier
-                    read_a(fa, tap + 1, 0);    // same window: no need to wait for the barrier
-                }
+                if (tap < 8) read_a(fa, tap + 1, 0);    // same window: no need to wait for the barrier
                 mma_rows(fb, 0, 2);
                 if (tap < 8) {
-                    __syncthreads();
-                    if (tap < 7) load_b(tap + 2, c0);
-                    else if (sl + 1 < nslab) load_b(0, c0 + CBK);
+                    __syncthreads();           // the next tap's tile has landed (DMA issued one tap ago, drained by this barrier's wait)
+                    // the tile after next goes into the buffer this tap has finished reading
+                    if (tap < 7) dma_b(Bcur, tap + 2, c0);
+                    else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
                     read_b(fa, Bnxt, 0);
                 }
                 mma_rows(fb, 2, 4);
@@ -639,8 +658,6 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         // the top of the tap, while half 0 (fetched during the previous tap) is multiplied; the NEXT tap's half-0 fragments while
         // the e4m3 group runs — pixel part before the tap's barrier, weight part after it.  (Carrying both fp16 halves across the
         // barrier needs 32 more registers than there are: spill reloads inside the tap loop, 3 % slower than no pipeline.)
-        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-        const u32x4 z4 = {0u, 0u, 0u, 0u};
         const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
         const int brow = wn * NPW + frow;
         const int bo0 = lds_off(brow, fq), bo1 = lds_off(brow, 4 + fq);
@@ -655,10 +672,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
             const int o = lds_off(arow, kk * 4 + fq);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ahi + o + i * 2048);
-                ah[i] = ((amask[i] >> tap) & 1u) ? v : zero;
-            }
+            for (int i = 0; i < 4; ++i)
+                ah[i] = *reinterpret_cast<const bf16x8*>(((amask[i] >> tap) & 1u) ? Ahi + o + i * 2048 : Zrow);
         };
         auto read_e4m3 = [&](const char* Bhi, int tap) {
             const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
@@ -671,10 +686,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
-                const u32x4 lo = *reinterpret_cast<const u32x4*>(Alo + o0 + i * 2048);
-                const u32x4 hi = *reinterpret_cast<const u32x4*>(Alo + o1 + i * 2048);
-                xl[i] = ok ? lo : z4;
-                xh[i] = ok ? hi : z4;
+                xl[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o0 + i * 2048 : Zrow);
+                xh[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o1 + i * 2048 : Zrow);
             }
         };
         auto mma_f16 = [&](const bf16x8 (&b)[JT], const bf16x8 (&a)[4]) {
@@ -702,9 +715,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             store_window();
             {
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
-                store_b(Bcur);
                 __syncthreads();
-                load_b(1, c0);
+                dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_f16_b(bh0, Bcur, 0);
                 read_f16_a(ah0, 0, 0);
             }
@@ -716,15 +728,12 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 read_e4m3(Bcur, tap);
                 mma_f16(bh0, ah0);
                 mma_f16(bh1, ah1);
-                if (tap < 8) {
-                    store_b(Bnxt);
-                    read_f16_a(ah0, tap + 1, 0);
-                }
+                if (tap < 8) read_f16_a(ah0, tap + 1, 0);
                 mma_e4m3(0, 2);
                 if (tap < 8) {
                     __syncthreads();
-                    if (tap < 7) load_b(tap + 2, c0);
-                    else if (sl + 1 < nslab) load_b(0, c0 + CBK);
+                    if (tap < 7) dma_b(Bcur, tap + 2, c0);
+                    else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
                     read_f16_b(bh0, Bnxt, 0);
                 }
                 mma_e4m3(2, 4);
@@ -1039,8 +1048,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const int wrows = dasv::WBM + 2 * W + 2;
         const size_t lds1 = (size_t)wrows * 128 * ((mode == 0 || mode == 3) ? 2 : 1) + 32768;
-        const bool dbuf = (mode == 0 || mode == 3) && lds1 + 32768 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
-        const size_t lds = lds1 + (dbuf ? 32768 : 0);
+        const bool dbuf = (mode == 0 || mode == 3) && lds1 + 32768 + 128 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
+        const size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
         const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
         if (S > 1) {
