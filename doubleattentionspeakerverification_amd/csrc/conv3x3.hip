@@ -368,13 +368,17 @@ constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 51
 
 // C1: the input activations are produced on the fly by a one-input-channel conv3x3+bias+ReLU over `mel` (conv11 fused
 // into conv12: its 786 MB output never exists in HBM).
-template <int PREC, bool DBUF, bool C1, int NWN>
+// IB = 16-pixel blocks per wave along the pixels: 4 -> 256-pixel tiles; 3 -> 192-pixel tiles, whose window leaves room for both
+// tile buffers on 80-column maps (90.6 KB + 64 KB), so conv12 runs the pipelined double-buffered loops too.
+template <int PREC, bool DBUF, bool C1, int NWN, int IB = 4>
 __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvParams p) {
+    static_assert(IB == 4 || (IB == 3 && NWN == 2 && !C1), "192-pixel tiles: 8-wave layout, activations from memory");
+    constexpr int TBM = 64 * IB;   // pixels per workgroup tile (4 waves along the pixels x IB blocks of 16)
     // NWN waves along the 128 output channels (x 4 along the 256 pixels): 2 -> 8 waves of 64 x 64 outputs, 4 -> 16 waves of
     // 64 x 32 (more waves per SIMD to overlap each other's barrier / fragment-read waits, at more LDS reads per MFMA)
     static_assert(NWN == 2 || NWN == 4, "wave layout");
     static_assert(!C1 || NWN == 2, "the fused first layer stages with the 512-thread layout");
-    constexpr int NT = 256 * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = (WMAXROWS * 16 + NT - 1) / NT, BCH = 1024 / NT;
+    constexpr int NT = 256 * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = ((64 * IB + 2 * 80 + 2) * 16 + NT - 1) / NT, BCH = 1024 / NT;
     constexpr bool X8 = PREC == PREC_X8;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr bool TWO = SPLIT || X8;      // two LDS planes per operand: bf16 hi | lo, or fp16 hi | the two e4m3 planes
@@ -382,7 +386,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int W = p.W, H = p.H, Cin = p.Cin;
-    const int wrows = WBM + 2 * W + 2;
+    const int wrows = TBM + 2 * W + 2;
     char* Ahi = smem;
     char* Alo = Ahi + (size_t)wrows * 128;   // X8: rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
     char* Bbase = Alo + (TWO ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
@@ -398,16 +402,16 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     const int tile = xcd * p.tiles_per_xcd + idx;
     if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m0 = mt * WBM, n0 = nt * CBN;
+    const int m0 = mt * TBM, n0 = nt * CBN;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / NWN, wn = wv % NWN;
     const int frow = lane & 15, fq = lane >> 4;
 
     // border masks of this lane's four A-fragment pixels
-    unsigned amask[4];
+    unsigned amask[IB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + frow;
+    for (int i = 0; i < IB; ++i) {
+        const int m = m0 + wm * (16 * IB) + i * 16 + frow;
         unsigned mask = 0;
         if (m < p.M) {
             const int w_ = m % W;
@@ -568,9 +572,9 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         for (int j = 0; j < JT; ++j) wsc[j] = sc[(size_t)(n0 + wn * NPW + j * 16 + frow) * 4 + (fq & 1)];
     }
 
-    f32x4 acc[4][JT];
+    f32x4 acc[IB][JT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IB; ++i)
 #pragma unroll
         for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -588,7 +592,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // Needs 128 fragment registers: possible since the window staging addresses stopped occupying ~60 registers (above).
     constexpr bool PIPE = SPLIT && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPE) {
-        struct Frags { bf16x8 bh[JT], bl[JT], ah[4], al[4]; };
+        struct Frags { bf16x8 bh[JT], bl[JT], ah[IB], al[IB]; };
         const int brow = wn * NPW + frow;
         const int boff0 = lds_off(brow, fq), boff1 = lds_off(brow, 4 + fq);   // tiles are 16 rows = 2048 bytes apart
         auto read_b = [&](Frags& f, const char* Bhi, int kk) {
@@ -600,10 +604,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             }
         };
         auto read_a = [&](Frags& f, int tap, int kk) {
-            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
             const int o = lds_off(arow, kk * 4 + fq);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < IB; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
                 f.ah[i] = *reinterpret_cast<const bf16x8*>(ok ? Ahi + o + i * 2048 : Zrow);
                 f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * 2048 : Zrow);
@@ -611,7 +615,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         };
         auto mma_rows = [&](const Frags& f, int i0, int i1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < IB; ++i) {
                 if (i < i0 || i >= i1) continue;
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
                 read_b(fb, Bcur, 1);
                 read_a(fb, tap, 1);
-                mma_rows(fa, 0, 4);
+                mma_rows(fa, 0, IB);
                 if (tap < 8) read_a(fa, tap + 1, 0);    // same window: no need to wait for the barrier
                 mma_rows(fb, 0, 2);
                 if (tap < 8) {
@@ -649,7 +653,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
                     read_b(fa, Bnxt, 0);
                 }
-                mma_rows(fb, 2, 4);
+                mma_rows(fb, 2, IB);
             }
         }
     } else if constexpr (X8 && DBUF && NWN == 2 && DASV_CONV_DIAG == 0) {
@@ -662,21 +666,21 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         const int brow = wn * NPW + frow;
         const int bo0 = lds_off(brow, fq), bo1 = lds_off(brow, 4 + fq);
         const int bq0 = 16384 + lds_off(brow, s1), bq1 = 16384 + lds_off(brow, s2);
-        bf16x8 bh0[JT], bh1[JT], ah0[4], ah1[4];
-        u32x4 wl[JT], wh[JT], xl[4], xh[4];
+        bf16x8 bh0[JT], bh1[JT], ah0[IB], ah1[IB];
+        u32x4 wl[JT], wh[JT], xl[IB], xh[IB];
         auto read_f16_b = [&](bf16x8 (&bh)[JT], const char* Bhi, int kk) {
 #pragma unroll
             for (int j = 0; j < JT; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (kk ? bo1 : bo0) + j * 2048);
         };
-        auto read_f16_a = [&](bf16x8 (&ah)[4], int tap, int kk) {
-            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+        auto read_f16_a = [&](bf16x8 (&ah)[IB], int tap, int kk) {
+            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
             const int o = lds_off(arow, kk * 4 + fq);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IB; ++i)
                 ah[i] = *reinterpret_cast<const bf16x8*>(((amask[i] >> tap) & 1u) ? Ahi + o + i * 2048 : Zrow);
         };
         auto read_e4m3 = [&](const char* Bhi, int tap) {
-            const int arow = wm * 64 + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
+            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
             const int o0 = lds_off(arow, s1), o1 = lds_off(arow, s2);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
@@ -684,21 +688,21 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 wh[j] = *reinterpret_cast<const u32x4*>(Bhi + bq1 + j * 2048);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < IB; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
                 xl[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o0 + i * 2048 : Zrow);
                 xh[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o1 + i * 2048 : Zrow);
             }
         };
-        auto mma_f16 = [&](const bf16x8 (&b)[JT], const bf16x8 (&a)[4]) {
+        auto mma_f16 = [&](const bf16x8 (&b)[JT], const bf16x8 (&a)[IB]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IB; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(b[j], a[i], acc[i][j]);
         };
         auto mma_e4m3 = [&](int i0, int i1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < IB; ++i) {
                 if (i < i0 || i >= i1) continue;
                 const i32x8 x8 = {(int)xl[i][0], (int)xl[i][1], (int)xl[i][2], (int)xl[i][3], (int)xh[i][0], (int)xh[i][1], (int)xh[i][2], (int)xh[i][3]};
 #pragma unroll
@@ -736,7 +740,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
                     read_f16_b(bh0, Bnxt, 0);
                 }
-                mma_e4m3(2, 4);
+                mma_e4m3(2, IB);
             }
         }
     } else
@@ -779,7 +783,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 const u32x4 z4 = {0u, 0u, 0u, 0u};
                 const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
-                const int brow = wn * NPW + frow, arow = wm * 64 + frow + shift;
+                const int brow = wn * NPW + frow, arow = wm * (16 * IB) + frow + shift;
                 const char* bp0 = Bhi + lds_off(brow, fq);
                 const char* bp1 = Bhi + lds_off(brow, 4 + fq);
                 const char* bq0 = Bhi + 16384 + lds_off(brow, s1);
@@ -788,16 +792,16 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 const char* ap1 = Ahi + lds_off(arow, 4 + fq);
                 const char* aq0 = Alo + lds_off(arow, s1);
                 const char* aq1 = Alo + lds_off(arow, s2);
-                bf16x8 bh0[JT], bh1[JT], ah0[4], ah1[4];
-                u32x4 wl[JT], wh[JT], xl[4], xh[4];
+                bf16x8 bh0[JT], bh1[JT], ah0[IB], ah1[IB];
+                u32x4 wl[JT], wh[JT], xl[IB], xh[IB];
 #pragma unroll
                 for (int j = 0; j < JT; ++j) bh0[j] = *reinterpret_cast<const bf16x8*>(bp0 + j * 2048);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ah0[i] = *reinterpret_cast<const bf16x8*>(ap0 + i * 2048);
+                for (int i = 0; i < IB; ++i) ah0[i] = *reinterpret_cast<const bf16x8*>(ap0 + i * 2048);
 #pragma unroll
                 for (int j = 0; j < JT; ++j) bh1[j] = *reinterpret_cast<const bf16x8*>(bp1 + j * 2048);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ah1[i] = *reinterpret_cast<const bf16x8*>(ap1 + i * 2048);
+                for (int i = 0; i < IB; ++i) ah1[i] = *reinterpret_cast<const bf16x8*>(ap1 + i * 2048);
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
                     wl[j] = *reinterpret_cast<const u32x4*>(bq0 + j * 2048);
@@ -805,19 +809,19 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 }
                 // hi * hi, first 32-channel half
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < IB; ++i) {
                     const bf16x8 a = ((amask[i] >> tap) & 1u) ? ah0[i] : zero;
 #pragma unroll
                     for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh0[j], a, acc[i][j]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < IB; ++i) {
                     xl[i] = *reinterpret_cast<const u32x4*>(aq0 + i * 2048);
                     xh[i] = *reinterpret_cast<const u32x4*>(aq1 + i * 2048);
                 }
                 // hi * hi, second half
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < IB; ++i) {
                     const bf16x8 a = ((amask[i] >> tap) & 1u) ? ah1[i] : zero;
 #pragma unroll
                     for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh1[j], a, acc[i][j]);
@@ -825,7 +829,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 // both cross terms of both halves: one K = 128 block-scaled e4m3 MFMA per tile.  A lane's eight operand registers are
                 // 16 bytes of block fq >> 1 (channels 16 (fq & 1) ...) and 16 bytes of block 2 + (fq >> 1) (channels 32 + 16 (fq & 1) ...)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < IB; ++i) {
                     const bool ok = (amask[i] >> tap) & 1u;
                     const u32x4 lo = ok ? xl[i] : z4, hi = ok ? xh[i] : z4;
                     const i32x8 x8 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -856,8 +860,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Bhi + 16384 + o);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int o = lds_off(wm * 64 + i * 16 + frow + shift, slot);
+                for (int i = 0; i < IB; ++i) {
+                    const int o = lds_off(wm * (16 * IB) + i * 16 + frow + shift, slot);
                     const bool ok = (amask[i] >> tap) & 1u;
                     bf16x8 ah = *reinterpret_cast<const bf16x8*>(Ahi + o);
                     bf16x8 al;
@@ -898,8 +902,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         for (int j = 0; j < JT; ++j) {
             const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            for (int i = 0; i < IB; ++i) {
+                const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
                 if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = acc[i][j];
             }
         }
@@ -915,8 +919,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < IB; ++i) {
+            const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
             if (m < p.M) {
                 f32x4 v = acc[i][j] + bv;
                 if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -1044,27 +1048,35 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.ntiles = Cout / dasv::CBN;
     static const int force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;   // initialised once, thread-safe
     if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr || row_span != nullptr)) {
-        p.mtiles = (p.M + dasv::WBM - 1) / dasv::WBM;
-        p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
-        const int wrows = dasv::WBM + 2 * W + 2;
-        const size_t lds1 = (size_t)wrows * 128 * ((mode == 0 || mode == 3) ? 2 : 1) + 32768;
-        const bool dbuf = (mode == 0 || mode == 3) && lds1 + 32768 + 128 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
-        const size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
         const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
+        const bool two = mode == 0 || mode == 3;
+        const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
+        const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
+        // 192-pixel tiles where the 256-pixel window leaves no room for the second tile buffer (80-column maps) but the 192-pixel
+        // one does: the launch then runs the pipelined double-buffered loops.  Not for the column-sum form (its partial rows are
+        // counted in 256-pixel tiles, dasv_conv3x3_colsum_rows) and not for split-K launches.
+        const bool t192 = two && lds256 + 32768 + 128 > 160 * 1024 && lds192 + 32768 + 128 <= 160 * 1024 && S == 1 &&
+                          colsum == nullptr && mel == nullptr;
+        const int tbm = t192 ? 192 : dasv::WBM;
+        p.mtiles = (p.M + tbm - 1) / tbm;
+        p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
+        const size_t lds1 = t192 ? lds192 : lds256;
+        const bool dbuf = two && lds1 + 32768 + 128 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
+        const size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         if (S > 1) {
             if (workspace_bytes < (size_t)S * p.M * Cout * sizeof(float)) return DASV_E_WORKSPACE;
             p.part = static_cast<float*>(workspace);
             p.ksplit = S;
         }
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8 * p.ksplit)), block(512);
-#define DASV_LAUNCH_WINDOW(SP, DB, CC, NW)                                                                           \
+#define DASV_LAUNCH_WINDOW(SP, DB, CC, NW, ...)                                                                      \
         do {                                                                                                         \
             constexpr int nwn_ = NW;                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC, nwn_>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC, nwn_, ##__VA_ARGS__>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (e != hipSuccess) return (int)e;                                                                      \
-            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC, nwn_>), grid, dim3(256 * nwn_), lds, s, p);    \
+            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC, nwn_, ##__VA_ARGS__>), grid, dim3(256 * nwn_), lds, s, p); \
         } while (0)
         // wave layout: 8 waves (64 x 64 outputs each) everywhere except the single-buffered split launches (80-column maps:
         // two barriers per tap), where 16 waves of 64 x 32 hide each other's waits: conv12 1.32 -> 1.20 ms (interleaved A/B)
@@ -1073,7 +1085,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true, 2);
             else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true, 2);
             else DASV_LAUNCH_WINDOW(2, false, true, 2);
-        } else if (mode == 3 && dbuf) DASV_LAUNCH_WINDOW(3, true, false, 2);
+        } else if (t192 && mode == 3) DASV_LAUNCH_WINDOW(3, true, false, 2, 3);
+        else if (t192) DASV_LAUNCH_WINDOW(0, true, false, 2, 3);
+        else if (mode == 3 && dbuf) DASV_LAUNCH_WINDOW(3, true, false, 2);
         else if (mode == 3) DASV_LAUNCH_WINDOW(3, false, false, 2);
         else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false, 2);
         else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false, 4);

@@ -12,7 +12,7 @@ from doubleattentionspeakerverification_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 other = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "_diag", "ab", "libconv_a.so")
-mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # 0 split-bf16, 1 bf16, 2 fp16 (pack not wired here), 3 split8
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 libs = [("A (other)", ctypes.CDLL(other)), ("B (in-tree)", _lib.load())]
 vp, ci = ctypes.c_void_p, ctypes.c_int
@@ -21,6 +21,9 @@ for _, l in libs:
     l.dasv_conv3x3_bias_relu_nhwc.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     l.dasv_conv3x3_pack_weights.restype = ci
     l.dasv_conv3x3_pack_weights.argtypes = [vp, vp, vp, ci, ci, vp]
+    if mode == 3:
+        l.dasv_conv3x3_pack_weights_x8.restype = ci
+        l.dasv_conv3x3_pack_weights_x8.argtypes = [vp, vp, vp, ci, ci, vp]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 layers = [("conv12", 128, 128, 300, 80), ("conv21", 128, 256, 150, 40), ("conv22", 256, 256, 150, 40),
@@ -32,8 +35,9 @@ for name, cin, cout, H, W in layers:
     w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, device=dev) * 0.1
     hi = torch.empty(cout * 9 * cin * 2, dtype=torch.uint8, device=dev)
-    lo = torch.empty_like(hi)
-    assert libs[1][1].dasv_conv3x3_pack_weights(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), cout, cin, stream) == 0
+    lo = torch.empty(cout * 9 * cin * 2 + 4 * cout, dtype=torch.uint8, device=dev)
+    pack = libs[1][1].dasv_conv3x3_pack_weights_x8 if mode == 3 else libs[1][1].dasv_conv3x3_pack_weights
+    assert pack(w.data_ptr(), hi.data_ptr(), lo.data_ptr(), cout, cin, stream) == 0
     ys = [torch.empty(B, H, W, cout, device=dev) for _ in libs]
 
     def run(k):
