@@ -66,6 +66,8 @@ class _VGG(nn.Module):
         # tested, but measured SLOWER end to end (6.74 vs 6.63 ms per [64,300,80] batch): conv12's loop is issue-bound and
         # the nine extra FMAs per staged value cost more than the saved traffic.  Off by default.
         self.fuse_first_block = False
+        # inference: activations between the split8 layers in the consumer's operand form (conv.conv3x3_x8); same results
+        self.packed_activations = True
         self._packed = {}
 
     def _mode(self):
@@ -93,6 +95,49 @@ class _VGG(nn.Module):
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self._mode(), grad_premasked, mask_input_grad,
                                           link_in, link_out)
 
+    def _packed_chain_ok(self, fdim, batch=None, frames=None):
+        """Inference in the split8 mode with every wide layer on the HIP kernel and channel counts the packed format takes:
+        activations between the layers are then written once in the consumer's operand form (conv.conv3x3_x8).  Not for small
+        batches: a packed output is written by the convolution's own epilogue, so those launches could not divide their channel
+        slabs over workgroups (split-K) — the fp32 chain is faster there (single utterances: train.py:117-133)."""
+        if self._mode() != "split8" or self.fuse_first_block or fdim > 80 or self.conv11.out_channels % 64 != 0:
+            return False
+        if batch is not None:
+            from . import _lib
+            h, w = _pooled(frames, self.n_blocks - 1), _pooled(fdim, self.n_blocks - 1)     # the last block's (smallest) maps
+            last = getattr(self, "conv%d1" % self.n_blocks)
+            if _lib.load().dasv_conv3x3_workspace_bytes(batch, h, w, last.in_channels, last.out_channels) != 0:
+                return False
+        for blk in range(1, self.n_blocks + 1):
+            for j in (1, 2):
+                c = getattr(self, "conv%d%d" % (blk, j))
+                if (blk, j) != (1, 1) and not (_hipconv.supported(c.in_channels, c.out_channels) and c.weight.dtype == torch.float32):
+                    return False
+        return True
+
+    def _pk(self, name, device):
+        key = (name, device.index)
+        packed = self._packed.get(key)
+        if packed is None:
+            packed = self._packed[key] = _hipconv.PackedConvWeights()
+        return packed
+
+    def _forward_map_packed(self, x):
+        """conv11 -> PACKED -> conv12 -> fp32 -> pool -> PACKED -> convX1 -> fp32 -> convX2 -> fp32 -> pool -> PACKED ... : bit-identical
+        to the fp32 chain (same conversion arithmetic, done by the producer instead of by every consumer workgroup).  Packed where
+        the producer writes it for free — the pools (measured 0.185 vs 0.183 ms) and conv11 (+0.02 ms for -0.07 ms in conv12); a
+        convolution's own epilogue does NOT write packed output here: its 8- and 4-byte stores cost the layer 18 % (measured,
+        tools/_diag/packed_pieces.py) against the 5-7 % a packed input saves the next one."""
+        dev = x.device
+        h = _hipconv.conv3x3_c1_bias_relu(x, self.conv11.weight, self.conv11.bias, pack=True)
+        for blk in range(1, self.n_blocks + 1):
+            c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
+            if blk > 1:
+                h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=False)
+            h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=(blk == 1), y_packed=False)
+            h = _hipconv.maxpool2x2_ceil(h, pack=blk < self.n_blocks)
+        return h
+
     def _hip_front(self, x):
         """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
         features themselves do not need a gradient."""
@@ -113,6 +158,8 @@ class _VGG(nn.Module):
         B, T, Fdim = paddedInputTensor.shape
         hip = self._hip_front(paddedInputTensor)
         grad = torch.is_grad_enabled()
+        if hip and not grad and self.packed_activations and self._packed_chain_ok(Fdim, B, T):
+            return self._forward_map_packed(paddedInputTensor)
         fused_first = False
         if hip:
             c12 = self.conv12

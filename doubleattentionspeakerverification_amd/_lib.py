@@ -53,6 +53,10 @@ SIGNATURES = {
     "dasv_maxpool2x2_bwd_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                               c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_x8_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_nhwc_supported": (c_int, [c_int, c_int, c_int]),
     "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_bwd_nhwc_f32": (c_int, [c_void_p] * 12 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
-           "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu",
+           "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu", "conv3x3_x8",
            "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
 
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
@@ -222,31 +222,66 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out)
 
 
-def conv3x3_c1_bias_relu(x, weight, bias):
+def conv3x3_c1_bias_relu(x, weight, bias, pack=False):
     """Inference-only relu(conv2d(x[:,None], weight, bias, padding 1)) for x [B,H,W] fp32; returns [B,Cout,H,W]
-    channels_last (NHWC memory).  One input channel: a pure HBM write stream (csrc/frontend_misc.hip)."""
+    channels_last (NHWC memory).  One input channel: a pure HBM write stream (csrc/frontend_misc.hip).
+    pack=True: the result is a PACKED activation tensor for conv3x3_x8(..., x_packed=True) (see there); Cout % 64 == 0."""
     lib = _lib.load()
     B, H, W = x.shape
     cout = weight.shape[0]
     x = x.contiguous()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    fn = lib.dasv_conv3x3_c1_bias_relu_x8_nhwc if pack else lib.dasv_conv3x3_c1_bias_relu_nhwc
     with torch.cuda.device(x.device):
-        rc = lib.dasv_conv3x3_c1_bias_relu_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
-                                                None if bias is None else bias.detach().data_ptr(), y.data_ptr(), B, H, W, cout, 1,
-                                                torch.cuda.current_stream(x.device).cuda_stream)
+        rc = fn(x.data_ptr(), weight.detach().contiguous().data_ptr(), None if bias is None else bias.detach().data_ptr(),
+                y.data_ptr(), B, H, W, cout, 1, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_c1_bias_relu_nhwc")
     return y
 
 
-def maxpool2x2_ceil(x):
-    """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W]."""
+def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False):
+    """Inference-only relu(conv2d(x, weight, bias, padding 1)) in the split8 mode on PACKED activations.
+
+    A packed tensor looks like the fp32 channels_last tensor it replaces (same shape, dtype, strides; C % 64 == 0) but every
+    256-byte slab of 64 channels holds the three operand planes the split8 kernel would make of the fp32 values while staging
+    its window: fp16 hi | e4m3(v) | e4m3((v - hi) * 2^12) (csrc/dasv_common.hpp, store_x8).  Made once by the producer —
+    this function with y_packed=True, conv3x3_c1_bias_relu(pack=True), maxpool2x2_ceil(pack=True) — it turns the consumer's
+    staging into a copy.  Results are bit-identical to the fp32 chain.  Only these three functions understand packed tensors:
+    never hand one to a torch op."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    if not x.is_cuda or x.dtype != torch.float32 or not supported(cin, cout) or W > 80:
+        raise RuntimeError("conv3x3_x8: unsupported shape/dtype %s %s" % (tuple(x.shape), x.dtype))
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        if x_packed:
+            raise RuntimeError("a packed activation tensor must keep its channels_last layout")
+        x = x.contiguous(memory_format=torch.channels_last)
+    packed = packed or PackedConvWeights()
+    hi, lo = packed.get(weight, "split8")
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), int(x_packed), hi.data_ptr(), lo.data_ptr(),
+                                                None if bias is None else bias.detach().data_ptr(), y.data_ptr(), int(y_packed),
+                                                None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, 1,
+                                                torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_x8_nhwc")
+    return y
+
+
+def maxpool2x2_ceil(x, pack=False):
+    """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W].
+    pack=True: the pooled map is written as a PACKED activation tensor (conv3x3_x8); C % 64 == 0."""
     lib = _lib.load()
     B, C, H, W = x.shape
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    fn = lib.dasv_maxpool2x2_ceil_x8_nhwc if pack else lib.dasv_maxpool2x2_ceil_nhwc
     with torch.cuda.device(x.device):
-        rc = lib.dasv_maxpool2x2_ceil_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+        rc = fn(x.data_ptr(), y.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_maxpool2x2_ceil_nhwc")
     return y
 

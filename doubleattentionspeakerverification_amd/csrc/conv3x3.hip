@@ -69,7 +69,6 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 
 // precision of the MFMA operands: split-bf16 (three products), bf16, fp16
 constexpr int PREC_SPLIT = 0, PREC_BF16 = 1, PREC_F16 = 2, PREC_X8 = 3;
-constexpr int X8_ACT_SHIFT = 12;   // activation residuals are stored as e4m3(r * 2^12)
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // staging conversion of two fp32 values: `hi` gets the packed 16-bit operands of the mode, `lo` the split residuals
@@ -91,25 +90,7 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// X8 staging of four fp32 values: fp16 hi (two words), e4m3 of the values, e4m3 of the scaled residuals.
-// v_cvt_pk_fp8_f32 rounds to nearest even and turns |v| >= 480 into NaN (checked: tools/fp8_mfma_check.hip): clamp first.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void cvt4_x8(f32x4 v, float rscale, uint32_t& h01, uint32_t& h23, uint32_t& v8, uint32_t& r8) {
-    // (36 -> 28 vector instructions per call against the first version: one packed fp16 conversion per pair instead of a scalar
-    // one for the residual and a packed one for the store; packed f32 subtract / multiply — this code never runs beside MFMAs;
-    // no zero-initialised destination for the first e4m3 pack)
-    const f32x2_t c01 = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
-    const f32x2_t c23 = {__builtin_amdgcn_fmed3f(v[2], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[3], -65504.f, 65504.f)};
-    const f16x2_t p0 = __builtin_convertvector(c01, f16x2_t), p1 = __builtin_convertvector(c23, f16x2_t);
-    const f32x2_t rs = {rscale, rscale};
-    const f32x2_t r01 = (c01 - __builtin_convertvector(p0, f32x2_t)) * rs, r23 = (c23 - __builtin_convertvector(p1, f32x2_t)) * rs;
-    h01 = __builtin_bit_cast(uint32_t, p0);
-    h23 = __builtin_bit_cast(uint32_t, p1);
-    const int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c01[1], -448.f, 448.f), (int)h01, false);
-    v8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c23[1], -448.f, 448.f), a, true);
-    const int b = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r01[1], -448.f, 448.f), (int)h23, false);
-    r8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r23[1], -448.f, 448.f), b, true);
-}
 
 // weights [Cout][Cin][3][3] fp32 (torch) -> X8 planes: fp16 [Cout][9][Cin] and, per (channel n, tap, 64-channel slab), 128
 // bytes { e4m3(r_w * 2^Sw[n]) x 64 | e4m3(w * 2^Sh[n]) x 64 }, then [Cout][4] scale bytes {127 - Sw, 127 - Sh, 0, 0} (the E8M0
@@ -196,6 +177,7 @@ struct ConvParams {
     int relu;
     // fused one-channel producer (window kernel, C1 variant): x is not read; its values are
     // relu(b1[c] + sum_tap w1[c][tap] * mel[pixel + tap]) computed while the window is staged
+    int x_packed, y_packed;   // split8 launches: x / y are PACKED activation tensors (dasv_common.hpp, store_x8) instead of fp32
     const float* mel;      // [B,H,W]
     const float* w1;       // [Cin][9]
     const float* b1;       // [Cin] or null
@@ -457,6 +439,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         for (int k = 0; k < WACHN; ++k) {
             if (wr0 + RSTEP * k < wrows) {
                 uint32_t h0, l0, h1, l1;
+                if (X8 && p.x_packed) {
+                    // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows
+                    *reinterpret_cast<f32x4*>((wach < 8 ? Ahi : Alo) + lds_off(wr0, wach & 7) + k * (RSTEP * 128)) = ra[k];
+                    continue;
+                }
                 if constexpr (X8) {
                     cvt4_x8(ra[k], (float)(1 << X8_ACT_SHIFT), h0, h1, l0, l1);
                     *reinterpret_cast<uint32_t*>(Alo + wl00 + k * (RSTEP * 128)) = l0;
@@ -907,6 +894,39 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         }
         return;
     }
+    // Coalescing epilogue (pipelined launches, plain output): a lane holds 4 channels of 16-pixel-strided pixels, so a direct store
+    // instruction writes 16 separate 64-byte pieces; measured (stores removed in a timing build) that epilogue costs 6.5 % of
+    // the seven layers and 11-13 % of the two-slab ones (3.5-5.4 us per tile).  Here the tile goes through LDS — [pixel][128
+    // channels] rows of 528 bytes (the 16-byte pad makes the b128 writes of 8 pixels hit 32 distinct banks) — and is written out
+    // as whole 512-byte pixel rows, two per wave-instruction.
+    if constexpr (PIPELINED) {
+        if (p.mask == nullptr && p.colsum == nullptr && !p.y_packed) {
+            constexpr int OP = 528;
+            __syncthreads();                     // every wave is done with the window and the tiles
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int nl = wn * NPW + j * 16 + (lane >> 4) * 4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    f32x4 v = acc[i][j] + bv;
+                    if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    *reinterpret_cast<f32x4*>(smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP + nl * 4) = v;
+                }
+            }
+            __syncthreads();
+            const int col = tid & 31;            // 16-byte chunk of a pixel's 512-byte row; 16 pixels per pass of the workgroup
+#pragma unroll
+            for (int k = 0; k < TBM / 16; ++k) {
+                const int pix = (tid >> 5) + 16 * k;
+                const int m = m0 + pix;
+                if (m < p.M)
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
+            }
+            return;
+        }
+    }
     // epilogue: D[row = channel][col = pixel]: lane holds channels n .. n+3 of pixel m
     float* red = reinterpret_cast<float*>(smem);   // [4 wm][128 channels] partial column sums (colsum only)
     if (p.colsum != nullptr) __syncthreads();      // every wave is done with the LDS tiles
@@ -927,7 +947,8 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
+                if (p.y_packed) store_x8(p.y, m, p.Cout, n, v);
+                else *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
                 csum += v;
             }
         }
@@ -1026,7 +1047,7 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
-                          const int* row_span = nullptr) {
+                          const int* row_span = nullptr, int x_packed = 0, int y_packed = 0) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1040,6 +1061,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.M = B * H * W; p.relu = relu;
     p.mel = mel; p.w1 = w1; p.b1 = b1;
     p.part = nullptr; p.ksplit = 1;
+    p.x_packed = x_packed; p.y_packed = y_packed;
+    if ((x_packed || y_packed) && (mode != 3 || mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
     p.row_span = row_span;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     hipStream_t s = (hipStream_t)stream;
@@ -1047,7 +1070,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     static const int force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;   // initialised once, thread-safe
     if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr || row_span != nullptr)) {
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
-        const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
+        // (a packed output is written by the convolution's own epilogue: no split-K form)
+        const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr && !y_packed) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
         const bool two = mode == 0 || mode == 3;
         const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
         const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
@@ -1061,7 +1085,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const size_t lds1 = t192 ? lds192 : lds256;
         const bool dbuf = two && lds1 + 32768 + 128 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
-        const size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
+        size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
+        if (dbuf && lds < (size_t)tbm * 528) lds = (size_t)tbm * 528;   // the coalescing epilogue's [pixel][528 B] image (narrow maps)
         if (S > 1) {
             if (workspace_bytes < (size_t)S * p.M * Cout * sizeof(float)) return DASV_E_WORKSPACE;
             p.part = static_cast<float*>(workspace);
@@ -1132,6 +1157,15 @@ int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, c
                                    dasv_stream_t stream) {
     return conv3x3_launch(mode, x, nullptr, nullptr, nullptr, w_hi, w_lo, bias, nullptr, nullptr, y, workspace, workspace_bytes, B,
                           H, W, Cin, Cout, relu, stream);
+}
+
+int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
+                                   int y_packed, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                                   int relu, dasv_stream_t stream) {
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
+                          static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
+                          x_packed ? 1 : 0, y_packed ? 1 : 0);
 }
 
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,

@@ -106,4 +106,42 @@ __device__ __forceinline__ float load_agent(const float* p) {
 
 __host__ __device__ inline int round_up_i(int a, int m) { return (a + m - 1) / m * m; }
 
+// ---- "split8" operand planes (csrc/conv3x3.hip, PREC_X8): fp32 value v = fp16 hi + residual r ------------------------------
+constexpr int X8_ACT_SHIFT = 12;   // activation residuals are stored as e4m3(r * 2^12)
+typedef float x8_f32x4 __attribute__((ext_vector_type(4)));
+typedef float x8_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 x8_f16x2 __attribute__((ext_vector_type(2)));
+// X8 staging of four fp32 values: fp16 hi (two words), e4m3 of the values, e4m3 of the scaled residuals.
+// v_cvt_pk_fp8_f32 rounds to nearest even and turns |v| >= 480 into NaN (checked: tools/fp8_mfma_check.hip): clamp first.
+__device__ __forceinline__ void cvt4_x8(x8_f32x4 v, float rscale, uint32_t& h01, uint32_t& h23, uint32_t& v8, uint32_t& r8) {
+    // (36 -> 28 vector instructions per call against the first version: one packed fp16 conversion per pair instead of a scalar
+    // one for the residual and a packed one for the store; packed f32 subtract / multiply — this code never runs beside MFMAs;
+    // no zero-initialised destination for the first e4m3 pack)
+    const x8_f32x2 c01 = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
+    const x8_f32x2 c23 = {__builtin_amdgcn_fmed3f(v[2], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[3], -65504.f, 65504.f)};
+    const x8_f16x2 p0 = __builtin_convertvector(c01, x8_f16x2), p1 = __builtin_convertvector(c23, x8_f16x2);
+    const x8_f32x2 rs = {rscale, rscale};
+    const x8_f32x2 r01 = (c01 - __builtin_convertvector(p0, x8_f32x2)) * rs, r23 = (c23 - __builtin_convertvector(p1, x8_f32x2)) * rs;
+    h01 = __builtin_bit_cast(uint32_t, p0);
+    h23 = __builtin_bit_cast(uint32_t, p1);
+    const int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c01[1], -448.f, 448.f), (int)h01, false);
+    v8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c23[1], -448.f, 448.f), a, true);
+    const int b = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r01[1], -448.f, 448.f), (int)h23, false);
+    r8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r23[1], -448.f, 448.f), b, true);
+}
+
+// A PACKED activation tensor has the geometry of the fp32 NHWC tensor it replaces — [pixels][C] floats, C % 64 == 0 — but every
+// 256-byte slab of 64 channels holds { fp16 hi x 64 | e4m3(v) x 64 | e4m3(r * 2^12) x 64 }: what the split8 convolution would make
+// of the fp32 values while staging its window, made ONCE by the producer (a conv epilogue, conv11, a pool).  The consumer's staging
+// is then a 16-byte copy with the addresses it already uses.  Four consecutive channels n .. n+3 (n % 4 == 0) of pixel `pix`:
+__device__ __forceinline__ void store_x8(float* y, long long pix, int C, int n, x8_f32x4 v) {
+    uint32_t h01, h23, v8, r8;
+    cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
+    char* slab = reinterpret_cast<char*>(y + (size_t)pix * C + (n & ~63));
+    const int cs = n & 63;
+    *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);
+    *reinterpret_cast<uint32_t*>(slab + 128 + cs) = v8;
+    *reinterpret_cast<uint32_t*>(slab + 192 + cs) = r8;
+}
+
 }  // namespace dasv

@@ -14,7 +14,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          int H, int W, int Cout, long long npix, int relu,
-                                                         const int* __restrict__ row_span) {
+                                                         const int* __restrict__ row_span, int pack) {
     const int quads = Cout >> 2;                 // lanes per pixel
     const int ppb = blockDim.x / quads;          // pixels per block iteration
     const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
         }
-        *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
+        if (pack) store_x8(y, pix, Cout, q * 4, o);     // PACKED output for a split8 consumer (dasv_common.hpp)
+        else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
     }
 }
 
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
 // ragged batch (pool_src != null): B == 1, Ho = total output rows; pool_src[ro] = {first input row, 1 if the window has a second row}
 __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int H, int W, int C, int Ho, int Wo, long long nvec,
-                                                              const int* __restrict__ pool_src) {
+                                                              const int* __restrict__ pool_src, int pack) {
     const int cq = C >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
@@ -75,7 +76,8 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
         if (hw) { const f4 v = *reinterpret_cast<const f4*>(base + C); m = __builtin_elementwise_max(m, v); }
         if (hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C); m = __builtin_elementwise_max(m, v); }
         if (hw && hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C + C); m = __builtin_elementwise_max(m, v); }
-        *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m;
+        if (pack) store_x8(y, op, C, q * 4, m);
+        else *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m;
     }
 }
 
@@ -211,16 +213,22 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __rest
 extern "C" {
 
 static int c1_launch(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cout, int relu,
-                     const int* row_span, dasv_stream_t stream) {
+                     const int* row_span, dasv_stream_t stream, int pack = 0) {
     if (x == nullptr || w == nullptr || y == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
+    if (pack && Cout % 64 != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
     const int ppb = 256 / (Cout / 4);
     long long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W,
-                       Cout, npix, relu, row_span);
+                       Cout, npix, relu, row_span, pack);
     return (int)hipGetLastError();
+}
+
+int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, int B, int H, int W,
+                                      int Cout, int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, static_cast<float*>(y_packed), B, H, W, Cout, relu, nullptr, stream, 1);
 }
 
 int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
@@ -242,7 +250,19 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo,
-                       nvec, static_cast<const int*>(nullptr));
+                       nvec, static_cast<const int*>(nullptr), 0);
+    return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, void* y_packed, int B, int H, int W, int C, dasv_stream_t stream) {
+    if (x == nullptr || y_packed == nullptr) return DASV_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 != 0) return DASV_E_SHAPE;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long nvec = (long long)B * Ho * Wo * (C / 4);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       static_cast<float*>(y_packed), H, W, C, Ho, Wo, nvec, static_cast<const int*>(nullptr), 1);
     return (int)hipGetLastError();
 }
 
@@ -255,7 +275,7 @@ int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_s
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows_in, W, C,
-                       rows_out, Wo, nvec, pool_src);
+                       rows_out, Wo, nvec, pool_src, 0);
     return (int)hipGetLastError();
 }
 

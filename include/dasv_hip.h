@@ -234,6 +234,22 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * PACKED activations (inference chains of mode-3 convolutions).  A packed tensor has the geometry of the fp32 NHWC tensor it
+ * replaces — [B,H,W,C] floats, C % 64 == 0 — but every 256-byte slab of 64 channels holds { fp16 hi x 64 | e4m3(v) x 64 |
+ * e4m3((v - hi) * 2^12) x 64 }: what the mode-3 convolution makes of fp32 values while it stages its window, made once by
+ * the producer.  Results are bit-identical to the fp32 chain (same conversion arithmetic); the consumer's staging becomes a
+ * copy.  Producers: the mode-3 convolution itself (y_packed), conv11 (dasv_conv3x3_c1_bias_relu_x8_nhwc), the max-pool
+ * (dasv_maxpool2x2_ceil_x8_nhwc: fp32 in, packed out).  Consumer: dasv_conv3x3_bias_relu_x8_nhwc with x_packed.
+ * Replaces nothing new in the reference: these are the calls above with one conversion moved (CNNs.py:72-86 in eval mode).
+ * ------------------------------------------------------------------------ */
+int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
+                                   int y_packed, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                                   int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, int B, int H, int W,
+                                      int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, void* y_packed, int B, int H, int W, int C, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * The same two launches on the front-end's own NHWC map: x / grad_x are [B, T, F, C] fp32 (what a channels_last
  * [B, C, T, F] tensor is in memory), i.e. the reference's `transpose(1, 2).contiguous().view(B, T, C*F)` (CNNs.py:88-89)
  * is folded into the kernels' addressing: feature d = c*F + f, D = C*F, dh = D / H = (C/H)*F.  All other tensors

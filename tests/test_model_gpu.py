@@ -820,3 +820,39 @@ def test_data_parallel_replicas_see_current_weights():
         for r, m in outs:
             assert float((r - m).abs().max()) <= 1e-5 * float(m.abs().max())
     assert float((outs[0][1] - outs[1][1]).abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,T", [(24, 300), (64, 150), (2, 61)])
+def test_packed_activation_chain_is_bit_identical_to_the_fp32_chain(B, T):
+    """Inference in the split8 mode writes the activations between the layers once, in the consumer's operand form (fp16 hi |
+    e4m3 | e4m3 residual per 64-channel slab): same conversion arithmetic, moved from every consumer workgroup to the producer,
+    so the front-end's output must not change by a single bit.  Also the single pieces against their fp32 forms."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    from doubleattentionspeakerverification_amd import conv as hc
+    torch.manual_seed(7)
+    fe = VGG4L(1024).to(DEV).eval()
+    mel = torch.randn(B, T, 80, device=DEV) * 2.0
+    with torch.no_grad():
+        # active for batches whose smallest maps fill the chip without split-K (a packed output has no split-K form); the
+        # single-utterance flow keeps the fp32 chain
+        assert fe.packed_activations and fe._packed_chain_ok(80, B, T) == (B >= 16)
+        a = fe.forward_map(mel)
+        fe.packed_activations = False
+        b = fe.forward_map(mel)
+        fe.packed_activations = True
+        assert a.shape == b.shape and torch.equal(a, b)
+        # pieces: packed conv11 -> conv12 == fp32 conv11 -> conv12; pool(pack) -> conv21(packed in / packed out) -> conv22
+        h11p = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias, pack=True)
+        h11 = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias)
+        y_p = hc.conv3x3_x8(h11p, fe.conv12.weight, fe.conv12.bias, None, x_packed=True)
+        y_f = hc.conv3x3_bias_relu(h11, fe.conv12.weight, fe.conv12.bias, None, "split8")
+        assert torch.equal(y_p, y_f)
+        pp, pf = hc.maxpool2x2_ceil(y_f, pack=True), hc.maxpool2x2_ceil(y_f)
+        z_p = hc.conv3x3_x8(hc.conv3x3_x8(pp, fe.conv21.weight, fe.conv21.bias, None, x_packed=True, y_packed=True),
+                            fe.conv22.weight, fe.conv22.bias, None, x_packed=True)
+        z_f = hc.conv3x3_bias_relu(hc.conv3x3_bias_relu(pf, fe.conv21.weight, fe.conv21.bias, None, "split8"),
+                                   fe.conv22.weight, fe.conv22.bias, None, "split8")
+        if B >= 16:
+            assert torch.equal(z_p, z_f)
+        else:   # small maps: the fp32 chain divides the channel slabs over workgroups (another summation order)
+            assert float((z_p - z_f).abs().max()) < 2e-5 * float(z_f.abs().max())
