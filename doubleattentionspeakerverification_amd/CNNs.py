@@ -123,18 +123,18 @@ class _VGG(nn.Module):
         return packed
 
     def _forward_map_packed(self, x):
-        """conv11 -> PACKED -> conv12 -> fp32 -> pool -> PACKED -> convX1 -> fp32 -> convX2 -> fp32 -> pool -> PACKED ... : bit-identical
-        to the fp32 chain (same conversion arithmetic, done by the producer instead of by every consumer workgroup).  Packed where
-        the producer writes it for free — the pools (measured 0.185 vs 0.183 ms) and conv11 (+0.02 ms for -0.07 ms in conv12); a
-        convolution's own epilogue does NOT write packed output here: its 8- and 4-byte stores cost the layer 18 % (measured,
-        tools/_diag/packed_pieces.py) against the 5-7 % a packed input saves the next one."""
+        """conv11 -> PACKED -> conv12 -> fp32 -> pool -> PACKED -> convX1 -> PACKED -> convX2 -> fp32 -> pool -> PACKED ... : bit-identical
+        to the fp32 chain (same conversion arithmetic, done by the producer instead of by every consumer workgroup).  A packed
+        input saves a layer 5-7 %.  The pools write packed for free (0.185 vs 0.183 ms), conv11 for +0.02 ms; a convolution's
+        epilogue only because it goes through LDS (coalescing epilogue): with 8- and 4-byte stores straight to memory the packed
+        output cost the producing layer 18 % (tools/_diag/packed_pieces.py)."""
         dev = x.device
         h = _hipconv.conv3x3_c1_bias_relu(x, self.conv11.weight, self.conv11.bias, pack=True)
         for blk in range(1, self.n_blocks + 1):
             c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
             if blk > 1:
-                h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=False)
-            h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=(blk == 1), y_packed=False)
+                h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=True)
+            h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=True, y_packed=False)
             h = _hipconv.maxpool2x2_ceil(h, pack=blk < self.n_blocks)
         return h
 

@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // channels] rows of 528 bytes (the 16-byte pad makes the b128 writes of 8 pixels hit 32 distinct banks) — and is written out
     // as whole 512-byte pixel rows, two per wave-instruction.
     if constexpr (PIPELINED) {
-        if (p.mask == nullptr && p.colsum == nullptr && !p.y_packed) {
+        if (p.mask == nullptr && p.colsum == nullptr) {
             constexpr int OP = 528;
             __syncthreads();                     // every wave is done with the window and the tiles
 #pragma unroll
@@ -912,7 +912,20 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 for (int i = 0; i < IB; ++i) {
                     f32x4 v = acc[i][j] + bv;
                     if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
-                    *reinterpret_cast<f32x4*>(smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP + nl * 4) = v;
+                    char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
+                    if (p.y_packed) {
+                        // PACKED output (dasv_common.hpp): the row image is the pixel's two 256-byte slabs; the small stores that
+                        // made a packed epilogue cost the layer 18 % when they went to memory are LDS stores here
+                        uint32_t h01, h23, v8, r8;
+                        cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
+                        char* slab = row + (nl >> 6) * 256;
+                        const int cs = nl & 63;
+                        *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint32_t*>(slab + 128 + cs) = v8;
+                        *reinterpret_cast<uint32_t*>(slab + 192 + cs) = r8;
+                    } else {
+                        *reinterpret_cast<f32x4*>(row + nl * 4) = v;
+                    }
                 }
             }
             __syncthreads();
