@@ -440,7 +440,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             if (wr0 + RSTEP * k < wrows) {
                 uint32_t h0, l0, h1, l1;
                 if (X8 && p.x_packed) {
-                    // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows
+                    // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows.
+                    // (Measured and dropped, round 2: the packed window by LDS-DMA, issued EARLY — behind the last tap's MFMAs, once
+                    // every wave holds that tap's fragments, one extra barrier per slab.  Bit-identical once out-of-tensor rows were
+                    // zero-filled, but 0-5 % SLOWER per layer: a wave issues ~10 one-KB pieces per slab in the middle of its MFMA
+                    // stream, and their issue cost — 60-185 cycles each beside MFMAs and fragment reads — eats the latency it hides.)
                     *reinterpret_cast<f32x4*>((wach < 8 ? Ahi : Alo) + lds_off(wr0, wach & 7) + k * (RSTEP * 128)) = ra[k];
                     continue;
                 }
