@@ -94,6 +94,19 @@ class ConvTimer:
             self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))
             return y
         convmod._launch = timed
+        inner8 = convmod.conv3x3_x8       # the packed-activation inference chain (CNNs._forward_map_packed) launches through this one
+
+        def timed8(x, weight, *a, **k):
+            if not self.active:
+                return inner8(x, weight, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(torch.cuda.current_stream(x.device))
+            y = inner8(x, weight, *a, **k)
+            e.record(torch.cuda.current_stream(x.device))
+            B, cin, H, W = x.shape
+            self.rec.append((s, e, 2.0 * 9 * cin * weight.shape[0] * B * H * W))
+            return y
+        convmod.conv3x3_x8 = timed8
 
     def summary(self):
         if not self.rec:
