@@ -15,10 +15,15 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          int H, int W, int Cout, long long npix, int relu,
                                                          const int* __restrict__ row_span, int pack) {
+    // A block walks chunks of C1_CHUNK consecutive pixels.  The one-channel input of a chunk (its pixels + W+1 of halo on each
+    // side, one contiguous run) is staged in LDS once; every lane then takes its nine taps from LDS.  (Round 1 had each of the
+    // Cout/4 lanes of a pixel issue the nine global loads itself: nine load instructions per 16-byte store kept the kernel at
+    // 2.8 TB/s of its 786 MB write for a [64,300,80] batch.)
+    extern __shared__ float c1_in[];                // [C1_CHUNK + 2 W + 2]
+    constexpr int C1_CHUNK = 512;
     const int quads = Cout >> 2;                 // lanes per pixel
     const int ppb = blockDim.x / quads;          // pixels per block iteration
     const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
-    if (pl >= ppb) return;
     float wr[4][9];
     f4 bv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -27,31 +32,48 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(size_t)(q * 4 + c) * 9 + t];
         if (bias != nullptr) bv[c] = bias[q * 4 + c];
     }
-    for (long long pix = (long long)blockIdx.x * ppb + pl; pix < npix; pix += (long long)gridDim.x * ppb) {
-        const int w_ = (int)(pix % W);
-        int h_ = (int)((pix / W) % H), hend = H;
-        if (row_span != nullptr) {   // ragged batch: image borders from the row table
-            const int r = (int)(pix / W), lo = row_span[2 * r];
-            h_ = r - lo;
-            hend = row_span[2 * r + 1] - lo;
+    const int halo = W + 1, span = C1_CHUNK + 2 * halo;
+    for (long long p0 = (long long)blockIdx.x * C1_CHUNK; p0 < npix; p0 += (long long)gridDim.x * C1_CHUNK) {
+        __syncthreads();                             // the previous chunk's readers are done
+        for (int i = threadIdx.x; i < span; i += blockDim.x) {
+            const long long g = p0 - halo + i;
+            c1_in[i] = (g >= 0 && g < npix) ? x[g] : 0.f;
         }
-        float in[9];
+        __syncthreads();
+        if (pl < ppb) {
+            const int nloc = (int)((npix - p0) < C1_CHUNK ? (npix - p0) : C1_CHUNK);
+            for (int l = pl; l < nloc; l += ppb) {
+                const long long pix = p0 + l;
+                const int w_ = (int)(pix % W);
+                int h_ = (int)((pix / W) % H), hend = H;
+                if (row_span != nullptr) {   // ragged batch: image borders from the row table
+                    const int r = (int)(pix / W), lo = row_span[2 * r];
+                    h_ = r - lo;
+                    hend = row_span[2 * r + 1] - lo;
+                }
+                const float* ctr = c1_in + l + halo;
+                float in[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-            in[t] = ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) ? x[pix + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                for (int t = 0; t < 9; ++t) {
+                    const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                    in[t] = ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) ? ctr[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                }
+                f4 o = bv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) o[c] = fmaf(in[t], wr[c][t], o[c]);
+                if (relu) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
+                }
+                // PACKED output for a split8 consumer (dasv_common.hpp).  (Its three small stores per lane are not what the packed
+                // form costs here — a wave-local LDS transpose into 16-byte stores changed nothing, 0.221 vs 0.225 ms: with 36 FMAs and
+                // the 28-instruction conversion per lane the kernel is bound by vector issue at this write rate.)
+                if (pack) store_x8(y, pix, Cout, q * 4, o);
+                else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
+            }
         }
-        f4 o = bv;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int t = 0; t < 9; ++t) o[c] = fmaf(in[t], wr[c][t], o[c]);
-        if (relu) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
-        }
-        if (pack) store_x8(y, pix, Cout, q * 4, o);     // PACKED output for a split8 consumer (dasv_common.hpp)
-        else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
     }
 }
 
@@ -218,10 +240,11 @@ static int c1_launch(const float* x, const float* w, const float* bias, float* y
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     if (pack && Cout % 64 != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
-    const int ppb = 256 / (Cout / 4);
-    long long blocks = (npix + ppb - 1) / ppb;
+    if (W > 4000) return DASV_E_SHAPE;                                   // the chunk's input run (512 + 2 W + 2 floats) lives in LDS
+    long long blocks = (npix + 511) / 512;                               // 512-pixel chunks (C1_CHUNK)
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, H, W,
+    const size_t lds = (size_t)(512 + 2 * W + 2) * sizeof(float);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, H, W,
                        Cout, npix, relu, row_span, pack);
     return (int)hipGetLastError();
 }
