@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // 128 zero bytes behind the tile buffers (pipelined loops): a border tap reads its fragment from here — ONE address select per
     // fragment instead of a data select per fragment register (probe: the selects cost 45 ns of a 1.9 us tap)
     char* Zrow = Bbase + (DBUF ? 65536 : 32768);
-    if (DBUF && TWO && NWN == 2 && !C1 && threadIdx.x < 8)
+    if (DBUF && NWN == 2 && !C1 && threadIdx.x < 8)
         *reinterpret_cast<u32x4*>(Zrow + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};   // visible after the first barrier of the loop
 
     const int per_split = p.tiles_per_xcd * 8;
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             const int piece = wu * 2 + k;
             const size_t off = ((size_t)(n0 + piece * 8 + lrow) * 9 + tap) * Cin + c0 + chunk * 8;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.whi + off), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
+            if constexpr (TWO) __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
         }
     };
     // X8: E8M0 block scales of the cross-term MFMA.  Block b of its K = 128 takes the scale byte of lane group b: blocks
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 
     // split-K: this workgroup covers channel slabs [sl_lo, nslab) of the Cin / 64
     const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
-    constexpr bool PIPELINED = TWO && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    constexpr bool PIPELINED = DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPELINED) dma_b(Bbase, 0, sl_lo * CBK);
     else load_b(0, sl_lo * CBK);
     int it = 0;
@@ -579,9 +579,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // weight fragments (new tile) right after it.  The two waves of a SIMD run in step, so without this both read, then both
     // multiply: two exposed read phases per tap.  tools/conv_core_probe.hip (same loop, LDS only): 2049 -> 1882 ns per tap.
     // Needs 128 fragment registers: possible since the window staging addresses stopped occupying ~60 registers (above).
-    constexpr bool PIPE = SPLIT && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    // (the single-MFMA modes, bf16 / fp16 operands, run the same loop on their one plane per operand)
+    constexpr bool PIPE = !X8 && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPE) {
-        struct Frags { bf16x8 bh[JT], bl[JT], ah[IB], al[IB]; };
+        struct Frags { bf16x8 bh[JT], bl[SPLIT ? JT : 1], ah[IB], al[SPLIT ? IB : 1]; };
         const int brow = wn * NPW + frow;
         const int boff0 = lds_off(brow, fq), boff1 = lds_off(brow, 4 + fq);   // tiles are 16 rows = 2048 bytes apart
         auto read_b = [&](Frags& f, const char* Bhi, int kk) {
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
                 f.bh[j] = *reinterpret_cast<const bf16x8*>(bp + j * 2048);
-                f.bl[j] = *reinterpret_cast<const bf16x8*>(bp + 16384 + j * 2048);
+                if constexpr (SPLIT) f.bl[j] = *reinterpret_cast<const bf16x8*>(bp + 16384 + j * 2048);
             }
         };
         auto read_a = [&](Frags& f, int tap, int kk) {
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             for (int i = 0; i < IB; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
                 f.ah[i] = *reinterpret_cast<const bf16x8*>(ok ? Ahi + o + i * 2048 : Zrow);
-                f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * 2048 : Zrow);
+                if constexpr (SPLIT) f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * 2048 : Zrow);
             }
         };
         auto mma_rows = [&](const Frags& f, int i0, int i1) {
@@ -608,9 +609,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 if (i < i0 || i >= i1) continue;
 #pragma unroll
                 for (int j = 0; j < JT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<PREC>(f.bh[j], f.ah[i], acc[i][j]);
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -1101,7 +1104,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         p.mtiles = (p.M + tbm - 1) / tbm;
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const size_t lds1 = t192 ? lds192 : lds256;
-        const bool dbuf = two && lds1 + 32768 + 128 <= 160 * 1024;   // measured: helps split mode, hurts bf16 mode
+        // both tile buffers (stride 32 KB also for the one-plane modes) whenever they fit: the launch then runs the pipelined loops
+        // (round 1 measured the double buffer alone as a loss for bf16 operands — with the un-pipelined loop)
+        const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
         size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         if (dbuf && lds < (size_t)tbm * 528) lds = (size_t)tbm * 528;   // the coalescing epilogue's [pixel][528 B] image (narrow maps)
         if (S > 1) {
@@ -1131,7 +1136,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         else if (mode == 3) DASV_LAUNCH_WINDOW(3, false, false, 2);
         else if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, false, 2);
         else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, false, 4);
+        else if (mode == 1 && dbuf) DASV_LAUNCH_WINDOW(1, true, false, 2);
         else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, false, 2);
+        else if (dbuf) DASV_LAUNCH_WINDOW(2, true, false, 2);
         else DASV_LAUNCH_WINDOW(2, false, false, 2);
 #undef DASV_LAUNCH_WINDOW
         if (p.ksplit > 1) {
