@@ -63,6 +63,7 @@ SIGNATURES = {
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_debug_last_variant": (ctypes.c_char_p, []),
     "dasv_debug_read_floor": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "dasv_debug_conv3x3_x8_w4_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 6 + [c_void_p]),
 }
 
 DTYPE_CODES = {"float32": 0, "bfloat16": 1, "float16": 2}

@@ -984,6 +984,271 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// EXPERIMENT, off by default (DASV_CONV_W4=1 or dasv_debug_conv3x3_x8_w4_nhwc): split8 forward on FOUR waves, one per SIMD.
+// Same tile, same LDS image, same MFMAs in the same order per accumulator as conv3x3_window_kernel<PREC_X8, true, false, 2> — the
+// results are bit-identical (tests/test_conv_gpu.py) — but each wave owns 128 pixels x 64 channels: 48 fragment reads per tap and
+// SIMD instead of 64, and no partner wave running in step with it.  A tap is 24 steps of four MFMAs (fp16 half 0 of pixel row i,
+// then the rows of half 1, then the e4m3 rows); a ring of four pixel fragments is read three steps ahead, across taps; the weight
+// fragments of a group are read during the group before it.  The synthetic loop promised 9 % (tools/conv_core4_probe.hip against
+// conv_core_probe.hip on one box, split-bf16 arithmetic, no tile stores: 1.63 vs 1.80 us per tap).  Measured in place, round 2,
+// same-box A/B on the six layers with maps up to 40 columns (tools/conv_w4_ab.py): 7-14 % SLOWER than the 8-wave kernel.  What the
+// probe does not have: with one wave per SIMD every vector instruction between MFMAs is exposed — the border selects alone cost 6 %
+// (16-22 % before they moved into the e4m3 steps), eight LDS-DMA issues per wave and tap sit in the MFMA stream with no partner to
+// cover them — and the prize the 512 registers were meant to buy, the next slab's window prefetched into registers, made it worse
+// (the compiler parks the 88 registers in AGPRs and spills: +28 %).  Kept as a tested starting point: it needs the DMA issued by
+// fewer, longer instructions and the selects gone (a zero-padded window image) before it can win.
+// Packed input only (the staging is a copy); no split-K, mask or column sums.
+template <int IB>
+__global__ void __launch_bounds__(256) conv3x3_x8w4_kernel(const ConvParams p) {
+    static_assert(IB == 8, "256-pixel tiles");
+    constexpr int TBM = 32 * IB, JT = 4, NS = 3 * IB, WMAXC = 40, WACHN = (TBM + 2 * WMAXC + 2 + 15) / 16;
+    static_assert(NS % 4 == 0, "ring of four fragments");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int W = p.W, H = p.H, Cin = p.Cin;
+    const int wrows = TBM + 2 * W + 2;
+    const int APL = wrows * 128;                 // one window plane: fp16 rows | rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
+    char* Bbase = smem + 2 * APL;                // 2 x { fp16 tile 16 KB | e4m3 tile 16 KB }
+    const int zoff = 2 * APL + 65536;            // 128 zero bytes: border taps read their fragments here
+    if (threadIdx.x < 8) *reinterpret_cast<u32x4*>(smem + zoff + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * p.tiles_per_xcd + idx;
+    if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * TBM, n0 = nt * CBN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    unsigned amask[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int m = m0 + wm * (16 * IB) + i * 16 + frow;
+        unsigned mask = 0;
+        if (m < p.M) {
+            const int w_ = m % W;
+            int h_ = (m / W) % H, hend = H;
+            if (p.row_span != nullptr) {
+                const int r = m / W, lo = p.row_span[2 * r];
+                h_ = r - lo;
+                hend = p.row_span[2 * r + 1] - lo;
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
+                if ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
+            }
+        }
+        amask[i] = mask;
+    }
+
+    // window staging: thread = 16-byte chunk (tid & 15) of window rows (tid >> 4) + 16 k; chunks 0-7 of a pixel's slab are its fp16
+    // row, 8-15 its two e4m3 rows.  Rows 16 apart share row & 7: one swizzled base + k * 2048.  Window rows outside the tensor are
+    // never read (their taps read the zero row), so their loads only need a valid address: the pixel index is clamped, nothing is
+    // zeroed, and the loop is branch-free up to the window's last (partial) group of 16 rows.
+    const int wach = tid & 15, wr0 = tid >> 4;
+    const int pixw0 = m0 - W - 1 + wr0;
+    const char* xbase = reinterpret_cast<const char*>(p.x);            // + (pixel * Cin + c0) * 4 + wach * 16 < 4 GB (host-checked)
+    const int wdst = (wach < 8 ? 0 : APL) + lds_off(wr0, wach & 7);
+    const int nfull = wrows >> 4;                                       // groups of 16 rows every thread takes part in
+    const bool wtail = wr0 < (wrows & 15);
+    f32x4 ra[WACHN];
+    auto load_window = [&](int c0) {
+        const unsigned cb = (unsigned)c0 * 4u + (unsigned)wach * 16u;
+#pragma unroll
+        for (int k = 0; k < WACHN; ++k) {
+            if (k < nfull || (k == nfull && wtail)) {
+                const int pix = min(max(pixw0 + 16 * k, 0), p.M - 1);
+                ra[k] = *reinterpret_cast<const f32x4*>(xbase + ((unsigned)pix * (unsigned)(Cin * 4) + cb));
+            }
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int k = 0; k < WACHN; ++k)
+            if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(smem + wdst + k * 2048) = ra[k];
+    };
+    // weight tile by LDS-DMA (see conv3x3_window_kernel): wave w moves 1-KB pieces 4w ... 4w+3 of both planes
+    const int wu = __builtin_amdgcn_readfirstlane(wv);
+    const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+    auto dma_piece = [&](char* Bdst, int tap, int c0, int k) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+        const int piece = wu * 4 + k;
+        const size_t off = ((size_t)(n0 + piece * 8 + lrow) * 9 + tap) * Cin + c0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.whi + off), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
+    };
+    int wsc[JT];
+    const int xsc = (fq & 1) ? 127 - X8_ACT_SHIFT : 127;
+    {
+        const uint8_t* sc = reinterpret_cast<const uint8_t*>(p.wlo) + (size_t)p.Cout * 9 * Cin * 2;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) wsc[j] = sc[(size_t)(n0 + wn * 64 + j * 16 + frow) * 4 + (fq & 1)];
+    }
+    f32x4 acc[IB][JT];
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: weights — row wn * 64 + j * 16 + frow of the tile, slot fq (+ 4) of the fp16 plane, slots s1 / s2 of the
+    // e4m3 plane; pixels — window row + tap shift, the same slots.  Tiles / pixel rows are 16 rows = 2048 bytes apart.
+    const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
+    const int brow = wn * 64 + frow;
+    const int bo0 = lds_off(brow, fq), bo1 = lds_off(brow, 4 + fq);
+    const int bq0 = 16384 + lds_off(brow, s1), bq1 = 16384 + lds_off(brow, s2);
+    const int arow0 = wm * (16 * IB) + frow + (W + 1);
+    // Fragment addresses of a tap, per pixel row i and kind (fp16 half 0 / half 1 / e4m3 low / high 16 bytes): the tap's swizzled
+    // base, or (zero row - i * 2048) where the tap falls outside the image for this lane's pixel; the row step i * 2048 is the read's
+    // instruction offset.  One wave per SIMD has no partner to hide vector instructions behind: the steps of the fp16 groups (four
+    // 16-cycle MFMAs) have room for two reads and nothing else, so the 6 instructions per row that make these addresses run in the
+    // e4m3 steps (four 32-cycle MFMAs) of the tap BEFORE — row i of the next tap at step 2 IB + i, when this tap's reads of that
+    // row have all been issued.
+    int adr[IB][4];
+    auto row_addresses = [&](int i, int tap) {
+        const int arow = arow0 + (tap / 3 - 1) * W + (tap % 3 - 1);
+        const bool ok = (amask[i] & (1u << tap)) != 0;
+        const int z = zoff - i * 2048;
+        adr[i][0] = ok ? lds_off(arow, fq) : z;
+        adr[i][1] = ok ? lds_off(arow, 4 + fq) : z;
+        adr[i][2] = ok ? APL + lds_off(arow, s1) : z;
+        adr[i][3] = ok ? APL + lds_off(arow, s2) : z;
+    };
+    bf16x8 bh0[JT], bh1[JT];
+    u32x4 wl[JT], wh[JT];
+    u32x4 ring0[4], ring1[4];            // pixel fragments, three steps ahead of their MFMAs (ring1: the e4m3 rows' second half)
+    // entry e of a tap's fragment stream: rows of fp16 half 0 | rows of half 1 | e4m3 rows
+    auto issue = [&](int e) {
+        const int i = e % IB, kind = e / IB, r = e & 3;
+        if (kind < 2) ring0[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][kind] + i * 2048);
+        else {
+            ring0[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][2] + i * 2048);
+            ring1[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][3] + i * 2048);
+        }
+    };
+
+    const int nslab = Cin / CBK;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_piece(Bbase, 0, 0, k);
+    load_window(0);
+    int it = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int c0 = sl * CBK;
+        if (sl > 0) load_window(c0);
+        if (sl > 0) asm volatile("s_barrier" ::: "memory");   // every wave has consumed the previous slab's last fragments
+        store_window();
+        __syncthreads();                                     // window visible; tile 0 of the slab has landed (vmcnt(0))
+        {
+            char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+            char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dma_piece(Bnxt, 1, c0, k);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                bh0[j] = *reinterpret_cast<const bf16x8*>(Bcur + bo0 + j * 2048);
+                bh1[j] = *reinterpret_cast<const bf16x8*>(Bcur + bo1 + j * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i) row_addresses(i, 0);
+            issue(0);
+            issue(1);
+            issue(2);
+        }
+        for (int tap = 0; tap < 9; ++tap, ++it) {
+            char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+            char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
+            // the tile that goes into this tap's buffer once every wave is done with it
+            const bool ddo = tap < 7 || (tap == 7 && sl + 1 < nslab);
+            const int dtap = tap < 7 ? tap + 2 : 0, dc0 = tap < 7 ? c0 : c0 + CBK;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int e = s + 3;
+                // next tap's addresses of row s - 2 IB (its last read of this tap, the e4m3 entry, went out three steps ago)
+                if (s >= 2 * IB && tap < 8) row_addresses(s - 2 * IB, tap + 1);
+                if (e < NS) issue(e);
+                else if (tap < 8) issue(e - NS);
+                // the e4m3 weight fragments during the fp16 groups: one read every second step
+                if (s < 2 * IB && (s & 1) == 0) {
+                    const int j = s >> 2;
+                    if ((s & 2) == 0) wl[j] = *reinterpret_cast<const u32x4*>(Bcur + bq0 + j * 2048);
+                    else wh[j] = *reinterpret_cast<const u32x4*>(Bcur + bq1 + j * 2048);
+                }
+                if (s == 2 * IB + 1 && tap < 8) {
+                    // the next tap's tile has landed (its DMA was issued one tap ago); every wave holds this tap's weight fragments
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                // after the barrier: both fp16 weight halves of the next tap (one read per step, the first half first) and the DMA of
+                // the tile after next into the buffer this tap has finished with
+                if (s >= 2 * IB + 1 && s < 2 * IB + 5 && tap < 8) {
+                    const int k = s - (2 * IB + 1);
+                    bh0[k] = *reinterpret_cast<const bf16x8*>(Bnxt + bo0 + k * 2048);
+                    if (ddo) dma_piece(Bcur, dtap, dc0, k);
+                }
+                if (s >= 2 * IB + 4 && s < 2 * IB + 8 && tap < 8) {
+                    const int k = s - (2 * IB + 4);
+                    bh1[k] = *reinterpret_cast<const bf16x8*>(Bnxt + bo1 + k * 2048);
+                }
+                const int i = s % IB, r = s & 3;
+                if (s < IB) {
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh0[j], __builtin_bit_cast(bf16x8, ring0[r]), acc[i][j]);
+                } else if (s < 2 * IB) {
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh1[j], __builtin_bit_cast(bf16x8, ring0[r]), acc[i][j]);
+                } else {
+                    const u32x4 lo = ring0[r], hi = ring1[r];
+                    const i32x8 x8 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                    for (int j = 0; j < JT; ++j) {
+                        const i32x8 w8 = {(int)wl[j][0], (int)wl[j][1], (int)wl[j][2], (int)wl[j][3], (int)wh[j][0], (int)wh[j][1], (int)wh[j][2], (int)wh[j][3]};
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, x8, acc[i][j], 0, 0, 0, wsc[j], 0, xsc);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // coalescing epilogue through LDS, as in conv3x3_window_kernel: [pixel][528 B] rows, whole 512-byte pixel rows to memory
+    constexpr int OP = 528;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            f32x4 v = acc[i][j] + bv;
+            if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+            char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
+            if (p.y_packed) {
+                uint32_t h01, h23, v8, r8;
+                cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
+                char* slab = row + (nl >> 6) * 256;
+                const int cs = nl & 63;
+                *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);
+                *reinterpret_cast<uint32_t*>(slab + 128 + cs) = v8;
+                *reinterpret_cast<uint32_t*>(slab + 192 + cs) = r8;
+            } else {
+                *reinterpret_cast<f32x4*>(row + nl * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int col = tid & 31;
+#pragma unroll 8
+    for (int k = 0; k < TBM / 8; ++k) {
+        const int pix = (tid >> 5) + 8 * k;
+        const int m = m0 + pix;
+        if (m < p.M)
+            *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
+    }
+}
+
 // y = f(sum_ks part[ks] + bias): the second launch of a split-K convolution (fixed summation order)
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, float* __restrict__ y,
@@ -1067,7 +1332,7 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
-                          const int* row_span = nullptr, int x_packed = 0, int y_packed = 0) {
+                          const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, int force_w4 = 0) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1115,6 +1380,18 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             p.ksplit = S;
         }
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8 * p.ksplit)), block(512);
+        // experimental four-wave kernel (see conv3x3_x8w4_kernel): opt-in, packed input, one pass, plain epilogue, maps up to 40 columns
+        static const int env_w4 = getenv("DASV_CONV_W4") != nullptr ? 1 : 0;
+        const bool w4_ok = mode == 3 && x_packed && dbuf && !t192 && W <= 40 && S == 1 && mask == nullptr && colsum == nullptr &&
+                           (unsigned long long)p.M * Cin * 4ull < (1ull << 32);
+        if (force_w4 && !w4_ok) return DASV_E_SHAPE;
+        if (w4_ok && (force_w4 || env_w4)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_x8w4_kernel<8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(dasv::conv3x3_x8w4_kernel<8>, dim3((unsigned)(p.tiles_per_xcd * 8)), dim3(256), lds, s, p);
+            return (int)hipGetLastError();
+        }
 #define DASV_LAUNCH_WINDOW(SP, DB, CC, NW, ...)                                                                      \
         do {                                                                                                         \
             constexpr int nwn_ = NW;                                                                                 \
@@ -1190,6 +1467,13 @@ int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f1
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
                           static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
                           x_packed ? 1 : 0, y_packed ? 1 : 0);
+}
+
+int dasv_debug_conv3x3_x8_w4_nhwc(const void* x, const void* w_f16, const void* w_e4m3, const float* bias, void* y, int y_packed,
+                                  int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
+    if (W > 40) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
+                          static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, relu, stream, nullptr, 1, y_packed ? 1 : 0, 1);
 }
 
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,

@@ -282,6 +282,11 @@ const char* dasv_debug_last_variant(void);
  * adds per-wave sums into scratch[0..2047] (>= 2048 floats, caller-zeroed).  bench.py times it beside the fused pooling
  * kernel: no kernel that streams x once can be faster than this on the same buffers. */
 int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream);
+/* Experiment (off by default; DASV_CONV_W4=1 routes eligible dasv_conv3x3_bias_relu_x8_nhwc launches to it): the split8
+ * convolution on four waves of 128 pixels x 64 channels.  PACKED input, maps of at most 40 columns, no workspace; results are
+ * bit-identical to dasv_conv3x3_bias_relu_x8_nhwc(x_packed = 1).  DASV_E_SHAPE where it does not apply. */
+int dasv_debug_conv3x3_x8_w4_nhwc(const void* x, const void* w_f16, const void* w_e4m3, const float* bias, void* y, int y_packed,
+                                  int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -822,6 +822,34 @@ def test_data_parallel_replicas_see_current_weights():
     assert float((outs[0][1] - outs[1][1]).abs().max()) > 0
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(8, 75, 20, 256, 512), (3, 38, 10, 128, 128), (2, 41, 40, 64, 256)])
+def test_experimental_four_wave_split8_kernel_is_bit_identical(B, H, W, cin, cout):
+    """csrc/conv3x3.hip keeps an off-by-default split8 kernel on four waves per workgroup (measured slower, kept as a starting
+    point): same MFMAs in the same order per output, so fp32 and packed outputs must equal the production kernel's bit for bit —
+    also on a ragged last tile and a partial window group."""
+    from doubleattentionspeakerverification_amd import conv as hc, _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    xf = torch.relu(torch.randn(B, cin, 2 * H, 2 * W, device=DEV)).contiguous(memory_format=torch.channels_last)
+    x = hc.maxpool2x2_ceil(xf, pack=True)
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, device=DEV) * 0.1
+    pk = hc.PackedConvWeights()
+    hi, lo = pk.get(w, "split8")
+    stream = torch.cuda.current_stream().cuda_stream
+    for y_packed in (0, 1):
+        ref = torch.zeros(B, H, W, cout, device=DEV)
+        got = torch.zeros(B, H, W, cout, device=DEV)
+        _lib.check(lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 1, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), ref.data_ptr(), y_packed,
+                                                      None, 0, B, H, W, cin, cout, 1, stream), "x8")
+        _lib.check(lib.dasv_debug_conv3x3_x8_w4_nhwc(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), b.data_ptr(), got.data_ptr(), y_packed,
+                                                     B, H, W, cin, cout, 1, stream), "x8 w4")
+        assert torch.equal(ref.view(torch.int32), got.view(torch.int32))
+    # wider maps are not its business
+    assert lib.dasv_debug_conv3x3_x8_w4_nhwc(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), b.data_ptr(), got.data_ptr(), 0,
+                                             B, H, 80, cin, cout, 1, stream) != 0
+
+
 @pytest.mark.parametrize("B,T", [(24, 300), (64, 150), (2, 61)])
 def test_packed_activation_chain_is_bit_identical_to_the_fp32_chain(B, T):
     """Inference in the split8 mode writes the activations between the layers once, in the consumer's operand form (fp16 hi |

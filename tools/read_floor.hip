@@ -69,6 +69,27 @@ __global__ void __launch_bounds__(512) read_like_dmha(const char* __restrict__ x
     if (lane == 0) atomicAdd(out + blockIdx.x, s);
 }
 
+// whole-utterance workgroups: NWG workgroups of 1024 threads, each reads its own contiguous 1/NWG of the buffer (NWG = 64: one
+// utterance per workgroup, all heads on one CU — no exchange between CUs would be needed, but only 64 CUs pull)
+template <int DEPTH>
+__global__ void __launch_bounds__(1024) read_chunk(const f4* __restrict__ x, long long nvec, float* __restrict__ out) {
+    const long long per = nvec / gridDim.x;
+    const f4* p = x + per * blockIdx.x;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    long long i = threadIdx.x;
+    for (; i + (DEPTH - 1) * 1024 < per; i += DEPTH * 1024) {
+        f4 v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) v[k] = p[i + k * 1024];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) acc += v[k];
+    }
+    for (; i < per; i += 1024) acc += p[i];
+    float s = acc[0] + acc[1] + acc[2] + acc[3];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, s);
+}
+
 int main() {
     const size_t bytes = 64ull * 300 * 512 * 4;
     const int NBUF = 8, REP = 200;
@@ -96,6 +117,8 @@ int main() {
 #define RS(G, D) time_it("read_sum grid " #G " x256, depth " #D, [&](int k) { hipLaunchKernelGGL(read_sum<D>, dim3(G), dim3(256), 0, 0, (const f4*)xs[k], nvec, out); })
     RS(256, 8); RS(512, 8); RS(1024, 4); RS(1024, 8); RS(2048, 4); RS(2048, 8); RS(4096, 2); RS(4096, 4); RS(8192, 2);
     time_it("read_like_dmha 256 x512 (pooling access shape)", [&](int k) { hipLaunchKernelGGL(read_like_dmha, dim3(256), dim3(512), 0, 0, xs[k], out); });
+#define RC(G, D) time_it("read_chunk " #G " x1024 (whole-utterance WGs), depth " #D, [&](int k) { hipLaunchKernelGGL(read_chunk<D>, dim3(G), dim3(1024), 0, 0, (const f4*)xs[k], nvec, out); })
+    RC(64, 8); RC(64, 16); RC(64, 32); RC(128, 8); RC(128, 16); RC(256, 8); RC(256, 16);
     // the same with the input hot in the Infinity Cache (one buffer): separates HBM from the CU load path
     time_it("read_like_dmha, ONE buffer (cache-hot)", [&](int) { hipLaunchKernelGGL(read_like_dmha, dim3(256), dim3(512), 0, 0, xs[0], out); });
     time_it("read_sum 2048 x256 d4, ONE buffer (cache-hot)", [&](int) { hipLaunchKernelGGL(read_sum<4>, dim3(2048), dim3(256), 0, 0, (const f4*)xs[0], nvec, out); });
