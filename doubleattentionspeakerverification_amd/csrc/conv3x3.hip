@@ -44,6 +44,17 @@ constexpr int CBM = 128, CBN = 128, CBK = 64;
 #ifndef DASV_CONV_DIAG
 #define DASV_CONV_DIAG 0
 #endif
+// -DDASV_CONV_STAMPS=1 (tools/conv_stamps.py): thread 0 of the launch's middle workgroup leaves 100 MHz timestamps at the phase
+// boundaries of its tile in dasv_conv_stamps (split8 pipelined loop only); read with dasv_debug_conv_stamps
+#ifndef DASV_CONV_STAMPS
+#define DASV_CONV_STAMPS 0
+#endif
+#if DASV_CONV_STAMPS
+__device__ unsigned long long dasv_conv_stamps[64];
+#define DASV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) dasv_conv_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DASV_STAMP(k) do { } while (0)
+#endif
 #ifndef DASV_CONV_SCHED
 #define DASV_CONV_SCHED 1   // reads-first scheduling hint (tools/conv_diag.py A/B)
 #endif
@@ -378,14 +389,21 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 
     const int per_split = p.tiles_per_xcd * 8;
     const int ks = blockIdx.x / per_split, inner = blockIdx.x - ks * per_split;
-    const int xcd = inner & 7, idx = inner >> 3;
+    const int xcd = inner & 7;
+    // (Measured and dropped, round 2: PERSISTENT tiles — one workgroup per CU walking its XCD's tiles in a loop, the thread index
+    // re-read behind an empty asm per tile so that nothing is hoisted out of the tile loop (otherwise ~50 vector registers are and
+    // the tap loops spill).  Bit-identical, no spills, and 0-7 % SLOWER per layer in the same-box A/B: the 3.5-4.5 us that
+    // tools/conv_stamps.py shows between a tile's last stamp and the launch time per round are not idle CU time — the stamping wave
+    // is not the slowest one, and the hardware dispatcher's dynamic placement beats the static stride.)
+    const int idx = inner >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / NWN, wn = wv % NWN;
+    const int frow = lane & 15, fq = lane >> 4;
     const int tile = xcd * p.tiles_per_xcd + idx;
     if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int m0 = mt * TBM, n0 = nt * CBN;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv / NWN, wn = wv % NWN;
-    const int frow = lane & 15, fq = lane >> 4;
+    DASV_STAMP(0);
 
     // border masks of this lane's four A-fragment pixels
     unsigned amask[IB];
@@ -425,29 +443,45 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     const int whi0 = lds_off(wr0, wach >> 1) + (wach & 1) * 8;
     const int wl00 = lds_off(wr0, wach >> 2) + (wach & 3) * 4, wl10 = lds_off(wr0, 4 + (wach >> 2)) + (wach & 3) * 4;
     f32x4 ra[WACHN];
+    // Rows of the window in groups of RSTEP: every thread takes part in the first `nfull` groups, the threads with wr0 < wrows %
+    // RSTEP in one more: per chunk one wave-uniform test instead of a per-lane predicate with its exec-mask branch.  Window rows
+    // outside the tensor (first / last tiles) are never used — a tap that falls outside the image reads the zero row or is
+    // deselected — so their loads only need a mapped address: the pixel index is clamped.  The index is re-read behind an empty asm
+    // per slab: as a slab-invariant expression the compiler computes all the clamped addresses once per tile and holds 2 registers
+    // per chunk across the tap loops, which have none to spare.
+    const int nfull = wrows / RSTEP;
+    const bool wtail = wr0 < wrows - nfull * RSTEP;
     auto load_window = [&](const float* xs) {
+        int pb = (int)pix0;
+        asm volatile("" : "+v"(pb));
+        const float* xc = xs - pix0 * Cin;          // = x + c0 + wach * 4
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
-            const long long pix = pix0 + RSTEP * k;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (wr0 + RSTEP * k < wrows && pix >= 0 && pix < p.M) v = *reinterpret_cast<const f32x4*>(xs + k * xstep);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};      // (defined on every path: a conditionally loaded ra[k] would stay live across the tap loops)
+            if (k < nfull || (k == nfull && wtail)) {
+                const int pix = min(max(pb + RSTEP * k, 0), p.M - 1);
+                v = *reinterpret_cast<const f32x4*>(xc + (size_t)pix * Cin);
+            }
             ra[k] = v;
         }
     };
     auto store_window = [&]() {
+        if (X8 && p.x_packed) {
+            // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows.
+            // (Measured and dropped, round 2: the packed window by LDS-DMA, issued EARLY — behind the last tap's MFMAs, once
+            // every wave holds that tap's fragments, one extra barrier per slab.  Bit-identical once out-of-tensor rows were
+            // zero-filled, but 0-5 % SLOWER per layer: a wave issues ~10 one-KB pieces per slab in the middle of its MFMA
+            // stream, and their issue cost — 60-185 cycles each beside MFMAs and fragment reads — eats the latency it hides.)
+            char* dst = (wach < 8 ? Ahi : Alo) + lds_off(wr0, wach & 7);
+#pragma unroll
+            for (int k = 0; k < WACHN; ++k)
+                if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(dst + k * (RSTEP * 128)) = ra[k];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
-            if (wr0 + RSTEP * k < wrows) {
+            if (k < nfull || (k == nfull && wtail)) {
                 uint32_t h0, l0, h1, l1;
-                if (X8 && p.x_packed) {
-                    // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows.
-                    // (Measured and dropped, round 2: the packed window by LDS-DMA, issued EARLY — behind the last tap's MFMAs, once
-                    // every wave holds that tap's fragments, one extra barrier per slab.  Bit-identical once out-of-tensor rows were
-                    // zero-filled, but 0-5 % SLOWER per layer: a wave issues ~10 one-KB pieces per slab in the middle of its MFMA
-                    // stream, and their issue cost — 60-185 cycles each beside MFMAs and fragment reads — eats the latency it hides.)
-                    *reinterpret_cast<f32x4*>((wach < 8 ? Ahi : Alo) + lds_off(wr0, wach & 7) + k * (RSTEP * 128)) = ra[k];
-                    continue;
-                }
                 if constexpr (X8) {
                     cvt4_x8(ra[k], (float)(1 << X8_ACT_SHIFT), h0, h1, l0, l1);
                     *reinterpret_cast<uint32_t*>(Alo + wl00 + k * (RSTEP * 128)) = l0;
@@ -618,6 +652,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             }
         };
         Frags fa, fb;
+        // (Measured and dropped, round 2: the last tap of a slab peeled off the tap loop, with the NEXT slab's window loads issued
+        // behind its second-half MFMAs, where half of the fragment registers are dead — tools/conv_stamps.py shows ~1.2 us of global
+        // latency exposed at every slab top.  The 256-pixel variants spill 32-44 registers for it and run 7-20 % slower; the
+        // 192-pixel ones fit and gain nothing measurable.)
         for (int sl = sl_lo; sl < nslab; ++sl) {
             const int c0 = sl * CBK;
             load_window(xrun + c0);
@@ -704,14 +742,18 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 }
             }
         };
+        DASV_STAMP(1);
         for (int sl = sl_lo; sl < nslab; ++sl) {
             const int c0 = sl * CBK;
+            DASV_STAMP(2 + 4 * (sl - sl_lo));
             load_window(xrun + c0);
             if (sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
+            DASV_STAMP(3 + 4 * (sl - sl_lo));
             store_window();
             {
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
                 __syncthreads();
+                DASV_STAMP(4 + 4 * (sl - sl_lo));
                 dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_f16_b(bh0, Bcur, 0);
                 read_f16_a(ah0, 0, 0);
@@ -734,6 +776,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 }
                 mma_e4m3(2, IB);
             }
+            DASV_STAMP(5 + 4 * (sl - sl_lo));
         }
     } else
     for (int sl = sl_lo; sl < nslab; ++sl) {
@@ -909,7 +952,9 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     if constexpr (PIPELINED) {
         if (p.mask == nullptr && p.colsum == nullptr) {
             constexpr int OP = 528;
+            DASV_STAMP(60);
             __syncthreads();                     // every wave is done with the window and the tiles
+            DASV_STAMP(61);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
                 const int nl = wn * NPW + j * 16 + (lane >> 4) * 4;
@@ -936,6 +981,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 }
             }
             __syncthreads();
+            DASV_STAMP(62);
             const int col = tid & 31;            // 16-byte chunk of a pixel's 512-byte row; 16 pixels per pass of the workgroup
 #pragma unroll
             for (int k = 0; k < TBM / 16; ++k) {
@@ -944,6 +990,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 if (m < p.M)
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
             }
+            DASV_STAMP(63);
             return;
         }
     }
@@ -1468,6 +1515,12 @@ int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f1
                           static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
                           x_packed ? 1 : 0, y_packed ? 1 : 0);
 }
+
+#if DASV_CONV_STAMPS
+int dasv_debug_conv_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasv::dasv_conv_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 int dasv_debug_conv3x3_x8_w4_nhwc(const void* x, const void* w_f16, const void* w_e4m3, const float* bias, void* y, int y_packed,
                                   int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
