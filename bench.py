@@ -107,6 +107,24 @@ class ConvTimer:
             self.rec.append((s, e, 2.0 * 9 * cin * weight.shape[0] * B * H * W))
             return y
         convmod.conv3x3_x8 = timed8
+        try:                                  # the ragged-batch launches (--workload varlen) go through ragged._conv_ragged
+            from doubleattentionspeakerverification_amd import ragged as ragmod
+        except ImportError:
+            ragmod = None
+        if ragmod is not None:
+            innerr = ragmod._conv_ragged
+
+            def timedr(x, conv, *a, **k):
+                if not self.active:
+                    return innerr(x, conv, *a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(torch.cuda.current_stream(x.device))
+                y = innerr(x, conv, *a, **k)
+                e.record(torch.cuda.current_stream(x.device))
+                rows, W, cin = x.shape
+                self.rec.append((s, e, 2.0 * 9 * cin * conv.out_channels * rows * W))
+                return y
+            ragmod._conv_ragged = timedr
 
     def summary(self):
         if not self.rec:

@@ -54,7 +54,7 @@ def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
         opt.step()
         assert abs(float(loss) - float(l2.detach())) < 1e-5
         for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
-            assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(b.abs().max()), k
+            assert float((a - b).detach().abs().max()) <= 1e-6 + 1e-5 * float(b.detach().abs().max()), k
         # bucket 0 (AM-softmax W, fc/BN, conv42 — with the never-firing b1.* / b3.* in the middle) waited for
         # finish() on every step.  From the second step on every bucket goes out from an autograd hook, during backward.
         assert not first_from_hook[0]
