@@ -41,6 +41,10 @@ SIGNATURES = {
     "dasv_conv3x3_bias_relu_ragged_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_ragged_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

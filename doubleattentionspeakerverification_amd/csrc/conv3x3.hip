@@ -1537,6 +1537,16 @@ int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_h
                           rows, W, Cin, Cout, relu, stream, row_span);
 }
 
+int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
+                                          int y_packed, const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W,
+                                          int Cin, int Cout, int relu, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
+                          static_cast<float*>(y), workspace, workspace_bytes, 1, rows, W, Cin, Cout, relu, stream, row_span,
+                          x_packed ? 1 : 0, y_packed ? 1 : 0);
+}
+
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
                              float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (mask == nullptr) return DASV_E_NULL;

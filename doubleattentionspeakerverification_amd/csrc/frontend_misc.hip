@@ -265,6 +265,12 @@ int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const 
     return c1_launch(x, w, bias, y, 1, rows, W, Cout, relu, row_span, stream);
 }
 
+int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, const int* row_span,
+                                             int rows, int W, int Cout, int relu, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return c1_launch(x, w, bias, static_cast<float*>(y_packed), 1, rows, W, Cout, relu, row_span, stream, 1);
+}
+
 int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream) {
     if (x == nullptr || y == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
@@ -299,6 +305,19 @@ int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_s
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows_in, W, C,
                        rows_out, Wo, nvec, pool_src, 0);
+    return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, void* y_packed, const int* pool_src, int rows_in, int rows_out, int W, int C,
+                                        dasv_stream_t stream) {
+    if (x == nullptr || y_packed == nullptr || pool_src == nullptr) return DASV_E_NULL;
+    if (rows_in <= 0 || rows_out <= 0 || W <= 0 || C <= 0 || C % 64 != 0) return DASV_E_SHAPE;
+    const int Wo = (W + 1) / 2;
+    const long long nvec = (long long)rows_out * Wo * (C / 4);
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       static_cast<float*>(y_packed), rows_in, W, C, rows_out, Wo, nvec, pool_src, 1);
     return (int)hipGetLastError();
 }
 

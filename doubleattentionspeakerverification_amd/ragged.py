@@ -54,15 +54,26 @@ def ragged_tables(lengths, levels, device):
     return spans, pools, lens
 
 
-def _conv_ragged(x, conv, packed, mode, span):
-    """x [rows, W, Cin] NHWC fp32 -> relu(conv3x3(x) + bias) [rows, W, Cout] with utterance borders from `span`."""
+def _conv_ragged(x, conv, packed, mode, span, x_packed=False, y_packed=False):
+    """x [rows, W, Cin] NHWC fp32 -> relu(conv3x3(x) + bias) [rows, W, Cout] with utterance borders from `span`.
+    x_packed / y_packed (split8 only): the tensors are PACKED activations (conv.conv3x3_x8)."""
     lib = _lib.load()
     rows, W, cin = x.shape
     cout = conv.out_channels
     hi, lo = packed.get(conv.weight, mode)
     y = torch.empty((rows, W, cout), dtype=torch.float32, device=x.device)
-    nws = lib.dasv_conv3x3_workspace_bytes(1, rows, W, cin, cout)
+    nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(1, rows, W, cin, cout)
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+    if x_packed or y_packed:
+        if mode != "split8":
+            raise RuntimeError("packed activations exist in the split8 mode only")
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(
+                x.data_ptr(), int(x_packed), hi.data_ptr(), lo.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
+                y.data_ptr(), int(y_packed), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin, cout, 1,
+                torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_x8_nhwc")
+        return y
     with torch.cuda.device(x.device):
         rc = lib.dasv_conv3x3_bias_relu_ragged_nhwc(
             _conv.MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
@@ -70,6 +81,24 @@ def _conv_ragged(x, conv, packed, mode, span):
             torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_nhwc")
     return y
+
+
+def _packed_chain_ok(front, rows, W, pools):
+    """True when no convolution of the ragged pass over `rows` stacked frames would divide its channel slabs over workgroups."""
+    lib = _lib.load()
+    for blk in range(1, front.n_blocks + 1):
+        for name in ("conv%d1" % blk, "conv%d2" % blk):
+            conv = getattr(front, name)
+            if conv.in_channels == 1:
+                if conv.out_channels % 64 != 0:
+                    return False
+                continue
+            if not _conv.supported(conv.in_channels, conv.out_channels) or W > 80:
+                return False
+            if lib.dasv_conv3x3_workspace_bytes(1, rows, W, conv.in_channels, conv.out_channels) != 0:
+                return False
+        rows, W = pools[blk - 1].shape[0], (W + 1) // 2
+    return True
 
 
 @torch.no_grad()
@@ -87,20 +116,33 @@ def front_end_ragged(front, utterances, mode=None):
     W = x.shape[1]
     spans, pools, lens = ragged_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    h = None
+    # split8: the activations between the layers in the consumer's operand form, as in CNNs._forward_map_packed — when no launch
+    # of the chain wants split-K (groups of utterances that fill the chip; a packed output has no split-K form)
+    chain = mode == "split8" and getattr(front, "packed_activations", False) and _packed_chain_ok(front, x.shape[0], W, pools)
+    h, h_packed = None, False
     for blk in range(1, front.n_blocks + 1):
         span = spans[blk - 1]
         for name in ("conv%d1" % blk, "conv%d2" % blk):
             conv = getattr(front, name)
+            first = name.endswith("1")
             if conv.in_channels == 1:
                 rows = x.shape[0]
                 h = torch.empty((rows, W, conv.out_channels), dtype=torch.float32, device=dev)
+                fn = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc if chain else lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc
                 with torch.cuda.device(dev):
-                    rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(
-                        x.data_ptr(), conv.weight.detach().contiguous().data_ptr(),
-                        None if conv.bias is None else conv.bias.detach().data_ptr(), h.data_ptr(), span.data_ptr(), rows, W,
-                        conv.out_channels, 1, stream)
+                    rc = fn(x.data_ptr(), conv.weight.detach().contiguous().data_ptr(),
+                            None if conv.bias is None else conv.bias.detach().data_ptr(), h.data_ptr(), span.data_ptr(), rows, W,
+                            conv.out_channels, 1, stream)
                 _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
+                h_packed = chain
+            elif chain:
+                key = (name, dev.index)
+                packed = front._packed.get(key)
+                if packed is None:
+                    packed = front._packed[key] = _conv.PackedConvWeights()
+                # convX1 hands convX2 a packed tensor; convX2's output goes to the pool in fp32 (the maximum needs all its bits)
+                h = _conv_ragged(h, conv, packed, mode, span, x_packed=h_packed, y_packed=first)
+                h_packed = first
             else:
                 if not _conv.supported(conv.in_channels, conv.out_channels):
                     raise RuntimeError("ragged front-end: layer %s (%d -> %d channels) is outside the HIP kernel's shapes"
@@ -113,11 +155,12 @@ def front_end_ragged(front, utterances, mode=None):
         rows_in, rows_out = h.shape[0], pools[blk - 1].shape[0]
         Wo = (W + 1) // 2
         y = torch.empty((rows_out, Wo, h.shape[2]), dtype=torch.float32, device=dev)
+        pack_out = chain and blk < front.n_blocks          # the last pool feeds the pooling layer: fp32
+        fn = lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc if pack_out else lib.dasv_maxpool2x2_ceil_ragged_nhwc
         with torch.cuda.device(dev):
-            rc = lib.dasv_maxpool2x2_ceil_ragged_nhwc(h.data_ptr(), y.data_ptr(), pools[blk - 1].data_ptr(), rows_in, rows_out, W,
-                                                      h.shape[2], stream)
+            rc = fn(h.data_ptr(), y.data_ptr(), pools[blk - 1].data_ptr(), rows_in, rows_out, W, h.shape[2], stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_ragged_nhwc")
-        h, W = y, Wo
+        h, W, h_packed = y, Wo, pack_out
     # [rows, F', C] -> [rows, C*F'] with feature = c*F' + f (CNNs.py:49-50 / 88-89)
     frames = h.permute(0, 2, 1).reshape(h.shape[0], h.shape[2] * h.shape[1])
     return frames, list(lens[-1])

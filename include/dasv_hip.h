@@ -214,6 +214,16 @@ int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const 
                                           int rows, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_src, int rows_in, int rows_out, int W, int C,
                                      dasv_stream_t stream);
+/* The same three on PACKED activations (split8 mode, see dasv_conv3x3_bias_relu_x8_nhwc): the producer writes each 64-channel
+ * slab as { fp16 x 64 | e4m3(v) x 64 | e4m3(r * 2^12) x 64 }, the consumer's staging becomes a copy.  Results are those of the
+ * fp32 ragged chain bit for bit when no launch of the chain wants split-K (dasv_conv3x3_workspace_bytes(1, rows, ...) == 0). */
+int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
+                                          int y_packed, const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W,
+                                          int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, const int* row_span,
+                                             int rows, int W, int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, void* y_packed, const int* pool_src, int rows_in, int rows_out, int W, int C,
+                                        dasv_stream_t stream);
 
 /* Backward of the max-pool above: gx [B,H,W,C] (OVERWRITTEN) from x [B,H,W,C] and gy [B,ceil(H/2),ceil(W/2),C]; the
  * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d

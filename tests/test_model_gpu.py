@@ -677,6 +677,37 @@ def test_ragged_batch_equals_one_utterance_per_forward():
         assert float((e2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), method
 
 
+def test_ragged_packed_activation_chain_is_bit_identical():
+    """A ragged group big enough to fill the chip without split-K runs the split8 layers on packed activations (ragged.py,
+    the `_x8` ragged entry points): same arithmetic, so the frame vectors must equal the fp32 ragged chain's bit for bit, and a
+    few utterances are checked against their own one-utterance forward."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    from doubleattentionspeakerverification_amd import ragged
+    torch.manual_seed(5)
+    fe = VGG4L(1024).to(DEV).eval()
+    g = np.random.RandomState(77)
+    lens = [int(n) for n in g.randint(150, 801, size=40)] + [151, 17]
+    utts = [torch.from_numpy(rnd(300 + i, n, 80)).to(DEV) for i, n in enumerate(lens)]
+    rows = sum(lens)
+    spans, pools, _ = ragged.ragged_tables(lens, fe.n_blocks, torch.device(DEV))
+    assert fe.conv_mode == "split8" and fe.packed_activations and ragged._packed_chain_ok(fe, rows, 80, pools)
+    a, ta = ragged.front_end_ragged(fe, utts)
+    fe.packed_activations = False
+    b, tb = ragged.front_end_ragged(fe, utts)
+    fe.packed_activations = True
+    assert ta == tb and torch.equal(a, b)
+    off = 0
+    with torch.no_grad():
+        for i, n in enumerate(ta):
+            if i in (0, 7, 40, 41):
+                f = fe(utts[i].unsqueeze(0))[0]
+                assert float((a[off:off + n] - f).abs().max()) <= 2e-5 * float(f.abs().max()) + 1e-7, i
+            off += n
+    # a small group keeps the fp32 chain (its narrow maps want split-K)
+    spans2, pools2, _ = ragged.ragged_tables(lens[:2], fe.n_blocks, torch.device(DEV))
+    assert not ragged._packed_chain_ok(fe, sum(lens[:2]), 80, pools2)
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 at its full size (default model, [64,300,80]), checked through properties that need no CPU run of
     39 GFLOP per utterance: (1) utterances are independent of their batch-mates — rows of the batched embedding equal the
