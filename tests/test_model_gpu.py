@@ -708,6 +708,42 @@ def test_ragged_packed_activation_chain_is_bit_identical():
     assert not ragged._packed_chain_ok(fe, sum(lens[:2]), 80, pools2)
 
 
+def test_two_streams_on_one_device_share_no_scratch():
+    """launches go to torch's current stream and no scratch is shared between calls.  The same module driven from
+    two side streams at once (groups of utterances alternating between them, so convolutions, pools and the fused pooling
+    kernel of different groups overlap in time) must give exactly what one stream gives."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd import ragged
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=400, num_spkrs=50, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(1234)
+    dev = torch.device(DEV)
+    net = SpeakerClassifier(p, dev).to(DEV).eval()
+    g = np.random.RandomState(1)
+    groups = [[torch.from_numpy(rnd(900 + 50 * k + i, int(n), 80)).to(DEV) for i, n in enumerate(g.randint(150, 801, size=24))]
+              for k in range(4)]
+    with torch.no_grad():
+        ref = [ragged.embed_ragged(net, gr) for gr in groups]
+        dense_ref = net.getEmbedding(torch.stack([gr[0][:150] for gr in groups]))
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        for st in side:
+            st.wait_stream(cur)
+        got, dense = [], []
+        for k, gr in enumerate(groups):
+            with torch.cuda.stream(side[k & 1]):
+                got.append(ragged.embed_ragged(net, gr))
+                dense.append(net.getEmbedding(torch.stack([q[0][:150] for q in groups])))
+        for st in side:
+            cur.wait_stream(st)
+        torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    for d in dense:
+        assert torch.equal(d, dense_ref)
+
+
 def test_config3_full_size_properties():
     """BASELINE config 3 at its full size (default model, [64,300,80]), checked through properties that need no CPU run of
     39 GFLOP per utterance: (1) utterances are independent of their batch-mates — rows of the batched embedding equal the
