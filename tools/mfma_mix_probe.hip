@@ -81,6 +81,32 @@ __global__ void __launch_bounds__(512) probe(const unsigned* __restrict__ seed, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else if (MODE == 3 || MODE == 4) {   // D / E: as B with the cross terms on fp6 (e2m3) / fp4 operands — is the K = 128 MFMA faster there?
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bh[j]), __builtin_bit_cast(f16x8, ah[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = MODE == 3 ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8[i], acc[i][j], 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
+                                          : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8[i], acc[i][j], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else if (MODE == 5) {   // F: the scaled fp8 MFMAs alone (16 per tap)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else if (MODE == 6) {   // G: the scaled fp6 MFMAs alone
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8[j], a8[i], acc[i][j], 2, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         } else {                   // C: 32 bf16 MFMAs
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -125,6 +151,10 @@ int main() {
         run("A split-bf16: 96 x 16x16x32 bf16", probe<0>, 96.0 * 2 * 16 * 16 * 32);
         run("B fp16 hi*hi + scaled fp8 cross: 32 + 16 (K=128)", probe<1>, 32.0 * 2 * 16 * 16 * 32 + 16.0 * 2 * 16 * 16 * 128);
         run("C single bf16: 32 x 16x16x32", probe<2>, 32.0 * 2 * 16 * 16 * 32);
+        run("D fp16 hi*hi + scaled fp6 (e2m3) cross: 32 + 16", probe<3>, 32.0 * 2 * 16 * 16 * 32 + 16.0 * 2 * 16 * 16 * 128);
+        run("E fp16 hi*hi + scaled fp4 cross: 32 + 16", probe<4>, 32.0 * 2 * 16 * 16 * 32 + 16.0 * 2 * 16 * 16 * 128);
+        run("F 16 x scaled fp8 K=128 alone", probe<5>, 16.0 * 2 * 16 * 16 * 128);
+        run("G 16 x scaled fp6 K=128 alone", probe<6>, 16.0 * 2 * 16 * 16 * 128);
     }
     CK(hipGetLastError());
     return 0;
