@@ -80,7 +80,7 @@ def test_train_step_matches_reference_adam_and_sgd():
             _, am = net.predictionLayer(net.preLayer(e2), lab, 0)
             loss = crit(am, lab)
             loss.backward()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         np.testing.assert_allclose(losses, g[tag + "_losses"], rtol=2e-5)
         nograd = sorted(n for n, q in net.named_parameters() if q.grad is None)
         assert nograd == sorted(str(n) for n in g[tag + "_nograd"])
