@@ -577,6 +577,20 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         typedef const __attribute__((address_space(1))) void* glb_ptr_t;
         const int wu = __builtin_amdgcn_readfirstlane(wv);
         const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+        if constexpr (!TWO) {
+            // one-plane modes: a wave-uniform base (tile, tap, slab: scalar arithmetic) + a 32-bit lane offset — 4 vector instructions
+            // per tap instead of the ~24 of the 64-bit per-lane products below (+3.1 % in the fp16 mode, same-box A/B).  In the
+            // two-plane modes the cheaper loop body makes the unroller take all nine taps apart (100 spilled registers in split8), and
+            // pinned to today's three taps per trip it still spills 35: they keep the long form.
+            const char* bh = reinterpret_cast<const char*>(p.whi) + (((size_t)n0 * 9 + tap) * Cin + c0) * 2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int piece = wu * 2 + k;
+                const unsigned vo = (((unsigned)piece * 8u + (unsigned)lrow) * (unsigned)(9 * Cin) + (unsigned)chunk * 8u) * 2u;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(bh + vo), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int piece = wu * 2 + k;
