@@ -677,6 +677,27 @@ def test_ragged_batch_equals_one_utterance_per_forward():
         assert float((e2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max()), method
 
 
+def test_packed_activation_chain_vgg3l_and_small_kernel_size():
+    """The packed chain is generic over the number of blocks and the channel widths: VGG3L (three blocks, F' = 10) and a
+    narrower VGG4L must also reproduce their fp32 chains bit for bit."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG3L, VGG4L
+    torch.manual_seed(11)
+    mel = torch.randn(32, 200, 80, device=DEV) * 2.0
+    for fe in (VGG3L(1024).to(DEV).eval(), VGG4L(512).to(DEV).eval()):
+        with torch.no_grad():
+            used = fe._packed_chain_ok(80, 32, 200)
+            a = fe.forward_map(mel)
+            fe.packed_activations = False
+            b = fe.forward_map(mel)
+            fe.packed_activations = True
+        assert a.shape == b.shape
+        if used:
+            assert torch.equal(a, b)
+        else:
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    assert VGG3L(1024).to(DEV)._packed_chain_ok(80, 32, 200)      # the wide three-block model does take the packed chain here
+
+
 def test_ragged_packed_activation_chain_is_bit_identical():
     """A ragged group big enough to fill the chip without split-K runs the split8 layers on packed activations (ragged.py,
     the `_x8` ragged entry points): same arithmetic, so the frame vectors must equal the fp32 ragged chain's bit for bit, and a
