@@ -57,6 +57,27 @@ def test_argument_validation_returns_codes_without_touching_the_gpu(lib_path):
     assert lib.dasv_dmha_bwd(0, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, 0, 1, 1, 1, 4, 4, 4, nul) == -1
 
 
+def test_split_k_plan_and_the_packed_chain_gate(lib_path):
+    """dasv_conv3x3_workspace_bytes is host arithmetic: zero means one pass fills the chip — the condition under which the
+    inference chain keeps its activations packed (a packed output has no split-K form).  Full batches of the default model
+    need no workspace in any layer; a single utterance does in the narrow-map layers; the new packed entry points validate
+    their arguments without a GPU."""
+    from doubleattentionspeakerverification_amd import _lib
+    lib = _lib.load()
+    layers = [(128, 128, 300, 80), (128, 256, 150, 40), (256, 256, 150, 40), (256, 512, 75, 20), (512, 512, 75, 20),
+              (512, 1024, 38, 10), (1024, 1024, 38, 10)]
+    for cin, cout, H, W in layers:
+        assert lib.dasv_conv3x3_workspace_bytes(64, H, W, cin, cout) == 0
+        assert lib.dasv_conv3x3_workspace_bytes(1, 64 * H, W, cin, cout) == 0      # a ragged group of the same footprint
+    assert lib.dasv_conv3x3_workspace_bytes(1, 19, 10, 1024, 1024) > 0
+    assert lib.dasv_conv3x3_workspace_bytes(1, 19, 10, 1024, 1024) % (19 * 10 * 1024 * 4) == 0   # S partial outputs
+    assert lib.dasv_conv3x3_packed_weight_bytes_x8(1024, 1024) == 1024 * 9 * 1024 * 2 + 1024 * 4
+    assert lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(None, 1, None, None, None, None, 0, None, None, 0, 100, 40, 128, 256, 1, None) < 0
+    assert lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(None, None, None, None, None, 100, 80, 128, 1, None) < 0
+    assert lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc(None, None, None, 100, 50, 80, 128, None) < 0
+    assert lib.dasv_debug_conv3x3_x8_w4_nhwc(None, None, None, None, None, 0, 8, 38, 10, 512, 1024, 1, None) < 0
+
+
 def test_kernels_are_built_for_gfx950_only(lib_path):
     blob = open(lib_path, "rb").read()
     assert b"gfx950" in blob
