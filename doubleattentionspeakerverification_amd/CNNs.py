@@ -11,8 +11,10 @@ checkpoints load with strict=True.
 Convolutions: the wide layers (Cin % 64 == 0, Cout % 128 == 0 — everything but conv11 at the reference's
 kernel sizes) run on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU` of csrc/conv3x3.hip on fp32
 NHWC activations; `conv_mode`:
-  "split8" (default) fp32-grade forward: fp16 products + block-scaled e4m3 cross terms (~1e-5 of the output scale per layer);
-           the backward pass of these layers runs in "split"
+  "split8" (default) fp32-grade forward: fp16 products + block-scaled e4m3 cross terms (~1e-5 of the output scale per layer) at
+           any magnitude of activations and weights — every tensor is scaled into the planes' range by an exact power of two
+           taken on the device from its range record (conv.new_ranges), Inf / NaN propagate; the backward pass of these layers
+           runs in "split"
   "split"  fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product, ~5e-6)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
@@ -84,16 +86,18 @@ class _VGG(nn.Module):
                 and self._mode() is not None and conv.weight.dtype == torch.float32
                 and _hipconv.supported(conv.in_channels, conv.out_channels))
 
-    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None):
+    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None, x_rec=None, y_rec=None):
+        """x_rec / y_rec: range records of h and of the result (split8 mode; None: h is measured by a pass over it).  Returns
+        (result, record of the result or None)."""
         conv = getattr(self, name)
         if not self._use_hip_conv(name, h):
-            return F.relu(conv(h))
+            return F.relu(conv(h)), None
         key = (name, h.device.index)   # nn.DataParallel replicas share this dict: one packed copy per device
         packed = self._packed.get(key)
         if packed is None:
             packed = self._packed[key] = _hipconv.PackedConvWeights()
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self._mode(), grad_premasked, mask_input_grad,
-                                          link_in, link_out)
+                                          link_in, link_out, x_rec, y_rec), y_rec
 
     def _packed_chain_ok(self, fdim, batch=None, frames=None):
         """Inference in the split8 mode with every wide layer on the HIP kernel and channel counts the packed format takes:
@@ -129,13 +133,28 @@ class _VGG(nn.Module):
         epilogue only because it goes through LDS (coalescing epilogue): with 8- and 4-byte stores straight to memory the packed
         output cost the producing layer 18 % (tools/_diag/packed_pieces.py)."""
         dev = x.device
-        h = _hipconv.conv3x3_c1_bias_relu(x, self.conv11.weight, self.conv11.bias, pack=True)
+        # one range record per tensor of the chain (conv.new_ranges): the input features' is measured (6 MB), every kernel fills
+        # its output's; a packed tensor is scaled by the exponent its producer left in its record
+        recs = _hipconv.new_ranges(dev, 1 + 3 * self.n_blocks)
+        r = iter(recs)
+        rx = next(r)
+        _lib = _hipconv._lib
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dasv_range_absmax_f32")
+        rh = next(r)
+        h = _hipconv.conv3x3_c1_bias_relu(x, self.conv11.weight, self.conv11.bias, pack=True, x_rec=rx, y_rec=rh)
         for blk in range(1, self.n_blocks + 1):
             c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
             if blk > 1:
-                h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=True)
-            h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=True, y_packed=False)
-            h = _hipconv.maxpool2x2_ceil(h, pack=blk < self.n_blocks)
+                ry = next(r)
+                h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=True, x_rec=rh, y_rec=ry)
+                rh = ry
+            ry = next(r)
+            h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=True, y_packed=False, x_rec=rh, y_rec=ry)
+            rh, ry = ry, next(r)
+            h = _hipconv.maxpool2x2_ceil(h, pack=blk < self.n_blocks, x_rec=rh, y_rec=ry)
+            rh = ry
         return h
 
     def _hip_front(self, x):
@@ -161,6 +180,10 @@ class _VGG(nn.Module):
         if hip and not grad and self.packed_activations and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_packed(paddedInputTensor)
         fused_first = False
+        # split8: one range record per tensor (see _forward_map_packed); rh = the record of h, None where h has none
+        x8 = hip and self._mode() == "split8"
+        recs = iter(_hipconv.new_ranges(paddedInputTensor.device, 3 * self.n_blocks)) if x8 else None
+        rh = None
         if hip:
             c12 = self.conv12
             fused_first = (self.fuse_first_block and not grad and Fdim <= 80 and c12.weight.dtype == torch.float32
@@ -174,9 +197,11 @@ class _VGG(nn.Module):
                                                           c12.weight, c12.bias, packed,
                                                           "split" if self._mode() == "split8" else self._mode())   # no fused form of split8
             elif grad:
-                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias)
+                rh = next(recs) if x8 else None
+                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias, rh)
             else:
-                h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias)
+                rh = next(recs) if x8 else None
+                h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias, y_rec=rh)
         else:
             h = paddedInputTensor.reshape(B, 1, T, Fdim)
             if self.channels_last and h.is_cuda:
@@ -191,14 +216,19 @@ class _VGG(nn.Module):
             pool_hip = hip and h.dtype == torch.float32
             l1, l2 = ({}, {}) if grad else (None, None)
             if not (hip and blk == 1):
-                h = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1)
+                h, rh = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1, x_rec=rh, y_rec=next(recs) if x8 else None)
             if not (fused_first and blk == 1):
-                h = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True, link_in=l2,
-                                    link_out=None if (hip and blk == 1) else l1)   # conv11's kernel sums its own bias gradient
+                h, rh = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True, link_in=l2,
+                                        link_out=None if (hip and blk == 1) else l1,   # conv11's kernel sums its own bias gradient
+                                        x_rec=rh, y_rec=next(recs) if x8 else None)
             if pool_hip and h.dtype == torch.float32:
-                h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2) if grad else _hipconv.maxpool2x2_ceil(h)
+                ry = next(recs) if (x8 and rh is not None) else None
+                h = (_hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2, x_rec=rh, y_rec=ry) if grad
+                     else _hipconv.maxpool2x2_ceil(h, x_rec=rh, y_rec=ry))
+                rh = ry
             else:
                 h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
+                rh = None
         return h
 
 

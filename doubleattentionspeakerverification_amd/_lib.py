@@ -32,49 +32,49 @@ SIGNATURES = {
     "dasv_dmha_bwd": (c_int, [c_int] + [c_void_p] * 13 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "dasv_conv3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "dasv_conv3x3_packed_weight_bytes_x8": (c_size_t, [c_int, c_int]),
-    "dasv_conv3x3_pack_weights_x8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_pack_weights_x8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dasv_range_absmax_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_bias_relu_nhwc_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_ragged_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_c1_bias_relu_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_maxpool2x2_ceil_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
-                                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_maxpool2x2_ceil_ragged_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_ragged_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_ragged_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                      c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_ragged_x8_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_c1_bias_relu_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_maxpool2x2_ceil_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_relu_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_bwd_colsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_bias_relu_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
-                                               c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_c1_bias_relu_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_maxpool2x2_ceil_x8_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_x8_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_x8_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_nhwc_supported": (c_int, [c_int, c_int, c_int]),
     "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_bwd_nhwc_f32": (c_int, [c_void_p] * 12 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_debug_last_variant": (ctypes.c_char_p, []),
     "dasv_debug_read_floor": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
-    "dasv_debug_conv3x3_x8_w4_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 6 + [c_void_p]),
 }
 
 DTYPE_CODES = {"float32": 0, "bfloat16": 1, "float16": 2}
 
 
 class DasvError(RuntimeError):
-    pass
+    code = 0   # the C ABI's return value (DASV_E_* < 0, hipError_t > 0)
 
 
 def lib_path():
@@ -99,8 +99,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
             fn.restype = res
             fn.argtypes = args
-        if lib.dasv_abi_version() != 1:
-            raise DasvError("libdasv_hip.so ABI version %d, expected 1" % lib.dasv_abi_version())
+        if lib.dasv_abi_version() != 2:
+            raise DasvError("libdasv_hip.so ABI version %d, expected 2" % lib.dasv_abi_version())
         _lib = lib
     return _lib
 
@@ -108,4 +108,6 @@ def load():
 def check(code, what):
     if code != 0:
         msg = load().dasv_error_string(code)
-        raise DasvError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))
+        err = DasvError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))
+        err.code = code
+        raise err

@@ -18,7 +18,7 @@ from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu", "conv3x3_x8",
-           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd"]
+           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of"]
 
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
 # "split8": fp32-grade forward on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8);
@@ -30,6 +30,24 @@ USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATe
 
 def supported(cin, cout):
     return cin % 64 == 0 and cout % 128 == 0
+
+
+def new_ranges(device, n=1):
+    """n zeroed RANGE RECORDS (include/dasv_hip.h): row i = (bits of max |v|, exponent of a packed tensor) of one activation
+    tensor.  The split8 convolution scales its operand planes by its input's record — on the device, no host round trip — and
+    every forward kernel of the front-end fills the record of what it writes.  One allocation per forward pass."""
+    return torch.zeros((n, 2), dtype=torch.int32, device=device)
+
+
+def range_of(x):
+    """Range record of a tensor no kernel of this library produced (one pass over it: the input features, a caller's tensor)."""
+    lib = _lib.load()
+    x = x if x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last) else x.contiguous()
+    rec = new_ranges(x.device)[0]
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_range_absmax_f32(x.data_ptr(), x.numel(), rec.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_range_absmax_f32")
+    return rec
 
 
 class PackedConvWeights:
@@ -51,23 +69,29 @@ class PackedConvWeights:
         self.key = None
         self.owner = None
 
-    def get(self, weight, mode="split"):
+    def get(self, weight, mode="split", bias=None):
+        """bias: the layer's bias (split8 only: its maximum enters the bound a packed output is scaled by)."""
         kind = _PACK_KIND[mode]
         cacheable = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
-        key = (weight.data_ptr(), weight._version, weight.device, kind)
+        key = (weight.data_ptr(), weight._version, weight.device, kind,
+               None if (bias is None or kind != 2) else (bias.data_ptr(), bias._version))
         if not (cacheable and key == self.key and self.owner is not None and self.owner() is weight):
             lib = _lib.load()
             cout, cin = weight.shape[0], weight.shape[1]
             n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
             nlo = max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cout, cin))   # the e4m3 plane carries its scale bytes behind it
             w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
-            if self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
+            if not cacheable or self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
+                # (weights that are not a leaf Parameter — DataParallel replicas, functional weights — get fresh planes per call:
+                # re-packing into shared buffers would race with a convolution still reading them on another stream)
                 self.hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
                 self.lo = torch.empty(nlo, dtype=torch.uint8, device=weight.device)
             with torch.cuda.device(weight.device):
                 stream = torch.cuda.current_stream(weight.device).cuda_stream
                 if kind == 2:
-                    rc = lib.dasv_conv3x3_pack_weights_x8(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)
+                    b = None if bias is None else bias.detach().float().contiguous()
+                    rc = lib.dasv_conv3x3_pack_weights_x8(w.data_ptr(), None if b is None else b.data_ptr(), self.hi.data_ptr(),
+                                                          self.lo.data_ptr(), cout, cin, stream)
                 elif kind == 1:
                     rc = lib.dasv_conv3x3_pack_weights_f16(w.data_ptr(), self.hi.data_ptr(), cout, cin, stream)
                 else:
@@ -88,15 +112,27 @@ def invalidate_packed_weights(module):
                     pk.invalidate()
 
 
-def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None):
+def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None):
     """colsum (with mask): a dict that receives 'gb' = per-channel sums of the masked output (fixed-order partial sums
-    from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel."""
+    from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel.
+    x_rec / y_rec (split8): range records of x (made here by a pass over x when the caller has none) and of y (optional)."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if mode == "split8" and x_rec is None:
+        x_rec = range_of(x)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if mask is not None:   # y = conv(x) where mask > 0 else 0 (no bias, no ReLU): the fused data-gradient form
+        if mode == "split8":
+            if mask is not None:
+                raise RuntimeError("split8 is a forward mode (no masked data-gradient form)")
+            nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+            rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 0, x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                    None if bias is None else bias.data_ptr(), y.data_ptr(), 0,
+                                                    None if y_rec is None else y_rec.data_ptr(),
+                                                    None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, relu, stream)
+        elif mask is not None:   # y = conv(x) where mask > 0 else 0 (no bias, no ReLU): the fused data-gradient form
             rows = lib.dasv_conv3x3_colsum_rows(B, H, W) if colsum is not None else 0
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             rc = lib.dasv_conv3x3_masked_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
@@ -142,9 +178,9 @@ def conv3x3_wgrad(x, g, mode="split"):
 
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out):
-        hi, lo = packed.get(weight, mode)
-        y = _launch(x, hi, lo, bias, weight.shape[0], mode)
+    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec):
+        hi, lo = packed.get(weight, mode, bias)
+        y = _launch(x, hi, lo, bias, weight.shape[0], mode, x_rec=x_rec, y_rec=y_rec)
         ctx.save_for_backward(x, weight, y)
         ctx.has_bias = bias is not None
         ctx.mode = mode
@@ -193,11 +229,11 @@ class _ConvReLUFn(torch.autograd.Function):
                 gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
             gw = gw2 if want_w else gw
             gb = gb2 if want_b else gb
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
-                      link_in=None, link_out=None):
+                      link_in=None, link_out=None, x_rec=None, y_rec=None):
     """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
 
     Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
@@ -208,7 +244,8 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
                        is multiplied by (x > 0) in the data-gradient kernel's epilogue.
     link_in / link_out are plain dicts shared between neighbouring calls: the kernel that produces a pre-masked gradient
     also leaves its per-channel sums (= the producer layer's bias gradient) in `link_out["gb"]`; the layer that receives
-    that gradient passes the same dict as `link_in` and skips its own reduction pass."""
+    that gradient passes the same dict as `link_in` and skips its own reduction pass.
+    x_rec / y_rec (mode "split8"): range records (new_ranges) of x — measured here with one pass over x when None — and of y."""
     if not x.is_cuda:
         raise RuntimeError("conv3x3_bias_relu runs on the GPU only (libdasv_hip.so); no CPU fallback")
     if x.dtype != torch.float32 or not supported(weight.shape[1], weight.shape[0]):
@@ -219,35 +256,46 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         mode = "split"   # the fp16 + e4m3 form exists in the window kernel (maps up to 80 columns) only
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
-    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out)
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec)
 
 
-def conv3x3_c1_bias_relu(x, weight, bias, pack=False):
+def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
     """Inference-only relu(conv2d(x[:,None], weight, bias, padding 1)) for x [B,H,W] fp32; returns [B,Cout,H,W]
     channels_last (NHWC memory).  One input channel: a pure HBM write stream (csrc/frontend_misc.hip).
-    pack=True: the result is a PACKED activation tensor for conv3x3_x8(..., x_packed=True) (see there); Cout % 64 == 0."""
+    y_rec: range record of the result (optional unless pack).
+    pack=True: the result is a PACKED activation tensor for conv3x3_x8(..., x_packed=True) (see there); Cout % 64 == 0;
+    x_rec = the range record of x (measured here when None)."""
     lib = _lib.load()
     B, H, W = x.shape
     cout = weight.shape[0]
     x = x.contiguous()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    fn = lib.dasv_conv3x3_c1_bias_relu_x8_nhwc if pack else lib.dasv_conv3x3_c1_bias_relu_nhwc
+    wp, bp = weight.detach().contiguous().data_ptr(), None if bias is None else bias.detach().data_ptr()
     with torch.cuda.device(x.device):
-        rc = fn(x.data_ptr(), weight.detach().contiguous().data_ptr(), None if bias is None else bias.detach().data_ptr(),
-                y.data_ptr(), B, H, W, cout, 1, torch.cuda.current_stream(x.device).cuda_stream)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if pack:
+            if y_rec is None:
+                raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
+            x_rec = range_of(x) if x_rec is None else x_rec
+            rc = lib.dasv_conv3x3_c1_bias_relu_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), wp, bp, y.data_ptr(), y_rec.data_ptr(), B, H, W,
+                                                       cout, 1, stream)
+        else:
+            rc = lib.dasv_conv3x3_c1_bias_relu_nhwc(x.data_ptr(), wp, bp, y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
+                                                    B, H, W, cout, 1, stream)
     _lib.check(rc, "dasv_conv3x3_c1_bias_relu_nhwc")
     return y
 
 
-def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False):
+def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_rec=None, y_rec=None):
     """Inference-only relu(conv2d(x, weight, bias, padding 1)) in the split8 mode on PACKED activations.
 
     A packed tensor looks like the fp32 channels_last tensor it replaces (same shape, dtype, strides; C % 64 == 0) but every
     256-byte slab of 64 channels holds the three operand planes the split8 kernel would make of the fp32 values while staging
-    its window: fp16 hi | e4m3(v) | e4m3((v - hi) * 2^12) (csrc/dasv_common.hpp, store_x8).  Made once by the producer —
-    this function with y_packed=True, conv3x3_c1_bias_relu(pack=True), maxpool2x2_ceil(pack=True) — it turns the consumer's
-    staging into a copy.  Results are bit-identical to the fp32 chain.  Only these three functions understand packed tensors:
-    never hand one to a torch op."""
+    its window: fp16(c) | e4m3(c) | e4m3((c - hi) * 2^12) with c = v * 2^E, E in the tensor's range record (csrc/dasv_common.hpp,
+    store_x8).  Made once by the producer — this function with y_packed=True, conv3x3_c1_bias_relu(pack=True),
+    maxpool2x2_ceil(pack=True) — it turns the consumer's staging into a copy.  Only these three functions understand packed
+    tensors: never hand one to a torch op.  x_rec: the record of x (required for a packed x; measured when None otherwise);
+    y_rec: the record of y (required for a packed y)."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = weight.shape[0]
@@ -258,30 +306,45 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False):
             raise RuntimeError("a packed activation tensor must keep its channels_last layout")
         x = x.contiguous(memory_format=torch.channels_last)
     packed = packed or PackedConvWeights()
-    hi, lo = packed.get(weight, "split8")
+    hi, lo = packed.get(weight, "split8", bias)
+    if x_rec is None:
+        if x_packed:
+            raise RuntimeError("a packed input needs the range record its producer filled")
+        x_rec = range_of(x)
+    if y_packed and y_rec is None:
+        raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-        rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), int(x_packed), hi.data_ptr(), lo.data_ptr(),
+        rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
                                                 None if bias is None else bias.detach().data_ptr(), y.data_ptr(), int(y_packed),
+                                                None if y_rec is None else y_rec.data_ptr(),
                                                 None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, 1,
                                                 torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_x8_nhwc")
     return y
 
 
-def maxpool2x2_ceil(x, pack=False):
+def maxpool2x2_ceil(x, pack=False, x_rec=None, y_rec=None):
     """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W].
-    pack=True: the pooled map is written as a PACKED activation tensor (conv3x3_x8); C % 64 == 0."""
+    x_rec / y_rec (together): the pooled map's range record is its input's.
+    pack=True: the pooled map is written as a PACKED activation tensor (conv3x3_x8), scaled by x_rec; C % 64 == 0."""
     lib = _lib.load()
     B, C, H, W = x.shape
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
+    if pack and y_rec is None:
+        raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
+    if pack and x_rec is None:
+        x_rec = range_of(x)
+    if x_rec is None or y_rec is None:
+        x_rec = y_rec = None
     y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     fn = lib.dasv_maxpool2x2_ceil_x8_nhwc if pack else lib.dasv_maxpool2x2_ceil_nhwc
     with torch.cuda.device(x.device):
-        rc = fn(x.data_ptr(), y.data_ptr(), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+        rc = fn(x.data_ptr(), None if x_rec is None else x_rec.data_ptr(), y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
+                B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_maxpool2x2_ceil_nhwc")
     return y
 
@@ -309,10 +372,10 @@ class _MaxPoolFn(torch.autograd.Function):
     """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward (arg-max recomputed)."""
 
     @staticmethod
-    def forward(ctx, x, relu_input, link_out):
+    def forward(ctx, x, relu_input, link_out, x_rec, y_rec):
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        y = maxpool2x2_ceil(x)
+        y = maxpool2x2_ceil(x, x_rec=x_rec, y_rec=y_rec)
         ctx.save_for_backward(x)
         ctx.relu_input = relu_input
         ctx.link_out = link_out
@@ -337,24 +400,24 @@ class _MaxPoolFn(torch.autograd.Function):
             else:
                 rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
-        return gx, None, None
+        return gx, None, None, None, None
 
 
-def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None):
+def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None, x_rec=None, y_rec=None):
     """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors.
 
     relu_input=True: x is the output of a conv3x3_bias_relu(..., grad_premasked=True) call and nothing else consumes it —
     the backward then also passes the gradient through that ReLU (one fused pass instead of two), and leaves that conv's
     bias gradient in `link_out["gb"]` (see conv3x3_bias_relu)."""
-    return _MaxPoolFn.apply(x, relu_input, link_out)
+    return _MaxPoolFn.apply(x, relu_input, link_out, x_rec, y_rec)
 
 
 class _Conv11ReLUFn(torch.autograd.Function):
     """relu(conv2d(x[:,None], w, b, padding 1)) for x [B,H,W] (no gradient w.r.t. x: x is the input feature map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        y = conv3x3_c1_bias_relu(x, weight, bias)
+    def forward(ctx, x, weight, bias, y_rec):
+        y = conv3x3_c1_bias_relu(x, weight, bias, y_rec=y_rec)
         ctx.save_for_backward(x.contiguous(), y)
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
@@ -376,9 +439,9 @@ class _Conv11ReLUFn(torch.autograd.Function):
                                               None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes, B, H, W, cout,
                                               torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_c1_bwd_nhwc")
-        return None, gw, gb
+        return None, gw, gb, None
 
 
-def conv3x3_c1_bias_relu_autograd(x, weight, bias):
+def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None):
     """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad."""
-    return _Conv11ReLUFn.apply(x, weight, bias)
+    return _Conv11ReLUFn.apply(x, weight, bias, y_rec)

@@ -103,41 +103,85 @@ __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// weights [Cout][Cin][3][3] fp32 (torch) -> X8 planes: fp16 [Cout][9][Cin] and, per (channel n, tap, 64-channel slab), 128
-// bytes { e4m3(r_w * 2^Sw[n]) x 64 | e4m3(w * 2^Sh[n]) x 64 }, then [Cout][4] scale bytes {127 - Sw, 127 - Sh, 0, 0} (the E8M0
-// block scales of the MFMA).  One workgroup per output channel: max |w| and max |r_w| first, then the planes.
-__global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const float* __restrict__ w, uint16_t* __restrict__ wh,
-                                                                       uint8_t* __restrict__ w8, int Cout, int Cin) {
-    __shared__ float red[2][4];
+// weights [Cout][Cin][3][3] fp32 (torch) -> X8 planes.  Every output channel n is scaled by its own exact power of two,
+// c = w * 2^Ew[n] with max |c| in [128, 256) (undone by the epilogue), so that weights of ANY magnitude sit in the normal range of
+// the fp16 plane:  fp16(c) as [Cout][9][Cin] and, per (channel n, tap, 64-channel slab), 128 bytes
+// { e4m3(r_c * 2^Sw[n]) x 64 | e4m3(c * 2^Sh[n]) x 64 }.  Behind the e4m3 planes: [Cout][4] scale bytes {127 - Sw, 127 - Sh, 0, 0}
+// (the E8M0 block scales of the MFMA) | [Cout] floats 2^-Ew[n] | { max_n sum_k |w[n][k]|, max_n |bias[n]|, 0, 0 } — the last two bound
+// the layer's output from its input's maximum (|y| <= amax_x * L1 + |b|), which is what a PACKED output is scaled by before any of
+// it exists.  One workgroup per output channel.
+__device__ __forceinline__ float block_max256(float v, float* red) {
+    v = group_max<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                                       uint16_t* __restrict__ wh, uint8_t* __restrict__ w8, int Cout, int Cin) {
+    __shared__ float red[4];
     const int o = blockIdx.x, tid = threadIdx.x, n = 9 * Cin;
     const float* wo = w + (size_t)o * n;
-    float mw = 0.f, mr = 0.f;
+    uint8_t* aux = w8 + (size_t)Cout * n * 2;
+    float* winv = reinterpret_cast<float*>(aux + (size_t)Cout * 4);
+    uint32_t* tail = reinterpret_cast<uint32_t*>(aux + (size_t)Cout * 8);   // zeroed by the host wrapper before this launch
+    float mw = 0.f, l1 = 0.f;
     for (int i = tid; i < n; i += 256) {
-        const float v = __builtin_amdgcn_fmed3f(wo[i], -65504.f, 65504.f);
+        const float v = wo[i];
         mw = fmaxf(mw, fabsf(v));
-        mr = fmaxf(mr, fabsf(v - (float)(_Float16)v));
+        l1 += fabsf(v);
     }
-    mw = group_max<64>(mw); mr = group_max<64>(mr);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = mw; red[1][tid >> 6] = mr; }
+    mw = block_max256(mw, red);
+    l1 = group_sum<64>(l1);
     __syncthreads();
-    mw = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    mr = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-    // scale exponents: max * 2^S in (64, 128] (well inside e4m3's 448); 0 for an all-zero row / exactly representable weights
+    if ((tid & 63) == 0) red[tid >> 6] = l1;
+    __syncthreads();
+    l1 = (red[0] + red[1]) + (red[2] + red[3]);
+    // (a NaN weight: fmaxf drops it, the sum keeps it — it reaches the bound as a NaN, and the planes carry it anyway)
+    const int Ew = x8_exp_for(__float_as_uint(mw));
+    const float sw = x8_pow2(Ew);
+    float mr = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float c = wo[i] * sw;
+        mr = fmaxf(mr, fabsf(c - (float)(_Float16)c));
+    }
+    mr = block_max256(mr, red);
+    const float mc = mw * sw;
+    // e4m3 scale exponents: max * 2^S in [64, 128) (well inside e4m3's 448); 0 for an all-zero row / exactly representable weights
     int eh = 0, el = 0;
-    if (mw > 0.f) { (void)frexpf(mw, &eh); eh = 7 - eh; }      // mw = f * 2^e, f in [0.5, 1)  ->  mw * 2^(7 - e) in [64, 128)
-    if (mr > 0.f) { (void)frexpf(mr, &el); el = 7 - el; }
+    if (mc > 0.f && mc < INFINITY) { (void)frexpf(mc, &eh); eh = 7 - eh; }      // mc = f * 2^e, f in [0.5, 1)  ->  mc * 2^(7 - e) in [64, 128)
+    if (mr > 0.f && mr < INFINITY) { (void)frexpf(mr, &el); el = 7 - el; }
     eh = max(-100, min(100, eh)); el = max(-100, min(100, el));
     const float sh = ldexpf(1.0f, eh), sl = ldexpf(1.0f, el);
-    uint8_t* sc = w8 + (size_t)Cout * n * 2;
-    if (tid == 0) { sc[o * 4 + 0] = (uint8_t)(127 - el); sc[o * 4 + 1] = (uint8_t)(127 - eh); sc[o * 4 + 2] = 0; sc[o * 4 + 3] = 0; }
+    if (tid == 0) {
+        aux[o * 4 + 0] = (uint8_t)(127 - el); aux[o * 4 + 1] = (uint8_t)(127 - eh); aux[o * 4 + 2] = 0; aux[o * 4 + 3] = 0;
+        winv[o] = x8_pow2(-Ew);
+        atomicMax(tail, __float_as_uint(l1) & 0x7fffffffu);
+    }
+    if (o == 0) {
+        float mb = 0.f;
+        uint32_t bb = 0u;
+        if (bias != nullptr)
+            for (int i = tid; i < Cout; i += 256) {
+                const uint32_t b = __float_as_uint(bias[i]) & 0x7fffffffu;
+                bb = b > bb ? b : bb;
+            }
+        mb = block_max256(__uint_as_float(bb <= 0x7f800000u ? bb : 0u), red);
+        // (a NaN bias: recorded as such)
+        uint32_t any_nan = bb > 0x7f800000u ? bb : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)any_nan, off); any_nan = t > any_nan ? t : any_nan; }
+        if ((tid & 63) == 0 && any_nan != 0u) atomicMax(tail + 1, any_nan);
+        if (tid == 0) atomicMax(tail + 1, __float_as_uint(mb));
+    }
     const int nslab = Cin / 64;
     for (int i = tid; i < n; i += 256) {
         const int c = i % Cin, tap = i / Cin;          // destination order (tap, cin)
-        const float v = __builtin_amdgcn_fmed3f(wo[(size_t)c * 9 + tap], -65504.f, 65504.f);
+        const float v = wo[(size_t)c * 9 + tap] * sw;
         const _Float16 h = (_Float16)v;
         wh[(size_t)o * n + i] = __builtin_bit_cast(uint16_t, h);
         const float r = (v - (float)h) * sl;
-        const int c8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r, -448.f, 448.f), __builtin_amdgcn_fmed3f(v * sh, -448.f, 448.f), 0, false);
+        const int c8 = __builtin_amdgcn_cvt_pk_fp8_f32(r, v * sh, 0, false);
         uint8_t* row = w8 + (((size_t)o * 9 + tap) * nslab + c / 64) * 128;
         row[c % 64] = (uint8_t)(c8 & 0xff);
         row[64 + c % 64] = (uint8_t)((c8 >> 8) & 0xff);
@@ -189,6 +233,8 @@ struct ConvParams {
     // fused one-channel producer (window kernel, C1 variant): x is not read; its values are
     // relu(b1[c] + sum_tap w1[c][tap] * mel[pixel + tap]) computed while the window is staged
     int x_packed, y_packed;   // split8 launches: x / y are PACKED activation tensors (dasv_common.hpp, store_x8) instead of fp32
+    const uint32_t* x_rec;    // range record of x (dasv_common.hpp): required in the split8 mode — the operand planes are scaled by it
+    uint32_t* y_rec;          // range record of y or null: [0] receives max |y| (atomic maximum), [1] the exponent of a packed y
     const float* mel;      // [B,H,W]
     const float* w1;       // [Cin][9]
     const float* b1;       // [Cin] or null
@@ -337,7 +383,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(const ConvParams p) 
                 const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu) v = relu_nan(v);
                     if (p.mask != nullptr && !(p.mask[(size_t)m * p.Cout + n] > 0.f)) v = 0.f;
                     p.y[(size_t)m * p.Cout + n] = v;
                 }
@@ -428,6 +474,35 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         amask[i] = mask;
     }
 
+    // split8: power-of-two scales from the range records (wave-uniform scalar loads).  sx = 2^Ex scales the activations into the
+    // operand planes' range (a packed x was made with the exponent in its record; an fp32 x is scaled while it is staged, by the
+    // exponent of its recorded maximum); the accumulators come out in units of 2^-(Ex + Ew[n]).  A packed OUTPUT needs its scale
+    // before any of it exists: |y| <= amax_x * max_n sum_k |w[n][k]| + max |b| (both left behind the weight planes by the pack kernel).
+    float sx = 1.f, sxinv = 1.f, sy = 1.f;
+    const float* winv = nullptr;
+    if constexpr (X8) {
+        const uint8_t* aux = reinterpret_cast<const uint8_t*>(p.wlo) + (size_t)p.Cout * 9 * Cin * 2;
+        winv = reinterpret_cast<const float*>(aux + (size_t)p.Cout * 4);
+        const uint32_t xa = p.x_rec[0];
+        const int Ex = p.x_packed ? (int)p.x_rec[1] : x8_exp_for(xa);
+        sx = x8_pow2(Ex);
+        sxinv = x8_pow2(-Ex);
+        if (p.y_packed) {
+            const float* tail = reinterpret_cast<const float*>(aux + (size_t)p.Cout * 8);
+            const float bound = (__uint_as_float(xa & 0x7fffffffu) * tail[0] + tail[1]) * 1.001f;   // margin: the sums are rounded
+            const int Ey = x8_exp_for(__float_as_uint(bound));
+            sy = x8_pow2(Ey);
+            if (blockIdx.x == 0 && threadIdx.x == 0) p.y_rec[1] = (uint32_t)Ey;
+        }
+    }
+    uint32_t amax_u = 0u;   // max of the sign-cleared bits of the values this lane stores (range record of y)
+    auto note4 = [&](const f32x4& v) {
+        const uint32_t a = __float_as_uint(v[0]) & 0x7fffffffu, b = __float_as_uint(v[1]) & 0x7fffffffu;
+        const uint32_t c = __float_as_uint(v[2]) & 0x7fffffffu, d = __float_as_uint(v[3]) & 0x7fffffffu;
+        amax_u = max(max(amax_u, a), max(b, max(c, d)));
+    };
+    auto relu4 = [&](f32x4 v) { return f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])}; };
+
     // A window staging: chunk q = tid + NT*k covers window row q/16, fp32 chunk q%16 (4 channels).  NT is a multiple of 16, so a
     // thread's chunks all sit in channel column tid & 15 and in rows (tid >> 4) + (NT/16) k: every global address is one running
     // pointer + k * (NT/16) * Cin floats and every LDS address one base + k * (NT/16) * 128 bytes (row & 7, which the swizzle uses,
@@ -483,7 +558,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             if (k < nfull || (k == nfull && wtail)) {
                 uint32_t h0, l0, h1, l1;
                 if constexpr (X8) {
-                    cvt4_x8(ra[k], (float)(1 << X8_ACT_SHIFT), h0, h1, l0, l1);
+                    cvt4_x8(ra[k], sx, h0, h1, l0, l1);
                     *reinterpret_cast<uint32_t*>(Alo + wl00 + k * (RSTEP * 128)) = l0;
                     *reinterpret_cast<uint32_t*>(Alo + wl10 + k * (RSTEP * 128)) = l1;
                 } else {
@@ -945,15 +1020,17 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         }
     }
 
-    if (p.ksplit > 1) {   // raw partial sums; conv3x3_splitk_reduce adds them up and applies bias / ReLU / mask
+    if (p.ksplit > 1) {   // partial sums (split8: already in output units); conv3x3_splitk_reduce adds them up and applies bias / ReLU / mask
         float* part = p.part + (size_t)ks * p.M * p.Cout;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n) * sxinv;
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
-                if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = acc[i][j];
+                if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = X8 ? acc[i][j] * sc : acc[i][j];
             }
         }
         return;
@@ -974,16 +1051,19 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 const int nl = wn * NPW + j * 16 + (lane >> 4) * 4;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n0 + nl) * sxinv;
 #pragma unroll
                 for (int i = 0; i < IB; ++i) {
-                    f32x4 v = acc[i][j] + bv;
-                    if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 v = (X8 ? acc[i][j] * sc : acc[i][j]) + bv;
+                    if (p.relu) v = relu4(v);
+                    if (m0 + wm * (16 * IB) + i * 16 + (lane & 15) < p.M) note4(v);
                     char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
                     if (p.y_packed) {
                         // PACKED output (dasv_common.hpp): the row image is the pixel's two 256-byte slabs; the small stores that
                         // made a packed epilogue cost the layer 18 % when they went to memory are LDS stores here
                         uint32_t h01, h23, v8, r8;
-                        cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
+                        cvt4_x8(v, sy, h01, h23, v8, r8);
                         char* slab = row + (nl >> 6) * 256;
                         const int cs = nl & 63;
                         *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);
@@ -1005,6 +1085,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
             }
             DASV_STAMP(63);
+            if (p.y_rec != nullptr) range_note(p.y_rec, amax_u);
             return;
         }
     }
@@ -1016,19 +1097,22 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n) * sxinv;
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
             if (m < p.M) {
-                f32x4 v = acc[i][j] + bv;
-                if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                f32x4 v = (X8 ? acc[i][j] * sc : acc[i][j]) + bv;
+                if (p.relu) v = relu4(v);
                 if (p.mask != nullptr) {
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
                 }
-                if (p.y_packed) store_x8(p.y, m, p.Cout, n, v);
+                note4(v);
+                if (p.y_packed) store_x8(p.y, m, p.Cout, n, v, sy);
                 else *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
                 csum += v;
             }
@@ -1043,290 +1127,34 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         __syncthreads();
         if (tid < 128) p.colsum[(size_t)mt * p.Cout + n0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     }
+    if (p.y_rec != nullptr) range_note(p.y_rec, amax_u);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// EXPERIMENT, off by default (DASV_CONV_W4=1 or dasv_debug_conv3x3_x8_w4_nhwc): split8 forward on FOUR waves, one per SIMD.
-// Same tile, same LDS image, same MFMAs in the same order per accumulator as conv3x3_window_kernel<PREC_X8, true, false, 2> — the
-// results are bit-identical (tests/test_conv_gpu.py) — but each wave owns 128 pixels x 64 channels: 48 fragment reads per tap and
-// SIMD instead of 64, and no partner wave running in step with it.  A tap is 24 steps of four MFMAs (fp16 half 0 of pixel row i,
-// then the rows of half 1, then the e4m3 rows); a ring of four pixel fragments is read three steps ahead, across taps; the weight
-// fragments of a group are read during the group before it.  The synthetic loop promised 9 % (tools/conv_core4_probe.hip against
-// conv_core_probe.hip on one box, split-bf16 arithmetic, no tile stores: 1.63 vs 1.80 us per tap).  Measured in place, round 2,
-// same-box A/B on the six layers with maps up to 40 columns (tools/conv_w4_ab.py): 7-14 % SLOWER than the 8-wave kernel.  What the
-// probe does not have: with one wave per SIMD every vector instruction between MFMAs is exposed — the border selects alone cost 6 %
-// (16-22 % before they moved into the e4m3 steps), eight LDS-DMA issues per wave and tap sit in the MFMA stream with no partner to
-// cover them — and the prize the 512 registers were meant to buy, the next slab's window prefetched into registers, made it worse
-// (the compiler parks the 88 registers in AGPRs and spills: +28 %).  Kept as a tested starting point: it needs the DMA issued by
-// fewer, longer instructions and the selects gone (a zero-padded window image) before it can win.
-// Packed input only (the staging is a copy); no split-K, mask or column sums.
-template <int IB>
-__global__ void __launch_bounds__(256) conv3x3_x8w4_kernel(const ConvParams p) {
-    static_assert(IB == 8, "256-pixel tiles");
-    constexpr int TBM = 32 * IB, JT = 4, NS = 3 * IB, WMAXC = 40, WACHN = (TBM + 2 * WMAXC + 2 + 15) / 16;
-    static_assert(NS % 4 == 0, "ring of four fragments");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const int W = p.W, H = p.H, Cin = p.Cin;
-    const int wrows = TBM + 2 * W + 2;
-    const int APL = wrows * 128;                 // one window plane: fp16 rows | rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
-    char* Bbase = smem + 2 * APL;                // 2 x { fp16 tile 16 KB | e4m3 tile 16 KB }
-    const int zoff = 2 * APL + 65536;            // 128 zero bytes: border taps read their fragments here
-    if (threadIdx.x < 8) *reinterpret_cast<u32x4*>(smem + zoff + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
-
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tile = xcd * p.tiles_per_xcd + idx;
-    if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m0 = mt * TBM, n0 = nt * CBN;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int frow = lane & 15, fq = lane >> 4;
-
-    unsigned amask[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        const int m = m0 + wm * (16 * IB) + i * 16 + frow;
-        unsigned mask = 0;
-        if (m < p.M) {
-            const int w_ = m % W;
-            int h_ = (m / W) % H, hend = H;
-            if (p.row_span != nullptr) {
-                const int r = m / W, lo = p.row_span[2 * r];
-                h_ = r - lo;
-                hend = p.row_span[2 * r + 1] - lo;
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
-                if ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
-            }
-        }
-        amask[i] = mask;
-    }
-
-    // window staging: thread = 16-byte chunk (tid & 15) of window rows (tid >> 4) + 16 k; chunks 0-7 of a pixel's slab are its fp16
-    // row, 8-15 its two e4m3 rows.  Rows 16 apart share row & 7: one swizzled base + k * 2048.  Window rows outside the tensor are
-    // never read (their taps read the zero row), so their loads only need a valid address: the pixel index is clamped, nothing is
-    // zeroed, and the loop is branch-free up to the window's last (partial) group of 16 rows.
-    const int wach = tid & 15, wr0 = tid >> 4;
-    const int pixw0 = m0 - W - 1 + wr0;
-    const char* xbase = reinterpret_cast<const char*>(p.x);            // + (pixel * Cin + c0) * 4 + wach * 16 < 4 GB (host-checked)
-    const int wdst = (wach < 8 ? 0 : APL) + lds_off(wr0, wach & 7);
-    const int nfull = wrows >> 4;                                       // groups of 16 rows every thread takes part in
-    const bool wtail = wr0 < (wrows & 15);
-    f32x4 ra[WACHN];
-    auto load_window = [&](int c0) {
-        const unsigned cb = (unsigned)c0 * 4u + (unsigned)wach * 16u;
-#pragma unroll
-        for (int k = 0; k < WACHN; ++k) {
-            if (k < nfull || (k == nfull && wtail)) {
-                const int pix = min(max(pixw0 + 16 * k, 0), p.M - 1);
-                ra[k] = *reinterpret_cast<const f32x4*>(xbase + ((unsigned)pix * (unsigned)(Cin * 4) + cb));
-            }
-        }
-    };
-    auto store_window = [&]() {
-#pragma unroll
-        for (int k = 0; k < WACHN; ++k)
-            if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(smem + wdst + k * 2048) = ra[k];
-    };
-    // weight tile by LDS-DMA (see conv3x3_window_kernel): wave w moves 1-KB pieces 4w ... 4w+3 of both planes
-    const int wu = __builtin_amdgcn_readfirstlane(wv);
-    const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
-    auto dma_piece = [&](char* Bdst, int tap, int c0, int k) {
-        typedef __attribute__((address_space(3))) void* lds_ptr_t;
-        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-        const int piece = wu * 4 + k;
-        const size_t off = ((size_t)(n0 + piece * 8 + lrow) * 9 + tap) * Cin + c0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.whi + off), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
-    };
-    int wsc[JT];
-    const int xsc = (fq & 1) ? 127 - X8_ACT_SHIFT : 127;
-    {
-        const uint8_t* sc = reinterpret_cast<const uint8_t*>(p.wlo) + (size_t)p.Cout * 9 * Cin * 2;
-#pragma unroll
-        for (int j = 0; j < JT; ++j) wsc[j] = sc[(size_t)(n0 + wn * 64 + j * 16 + frow) * 4 + (fq & 1)];
-    }
-    f32x4 acc[IB][JT];
-#pragma unroll
-    for (int i = 0; i < IB; ++i)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses: weights — row wn * 64 + j * 16 + frow of the tile, slot fq (+ 4) of the fp16 plane, slots s1 / s2 of the
-    // e4m3 plane; pixels — window row + tap shift, the same slots.  Tiles / pixel rows are 16 rows = 2048 bytes apart.
-    const int s1 = 4 * (fq >> 1) + (fq & 1), s2 = s1 + 2;
-    const int brow = wn * 64 + frow;
-    const int bo0 = lds_off(brow, fq), bo1 = lds_off(brow, 4 + fq);
-    const int bq0 = 16384 + lds_off(brow, s1), bq1 = 16384 + lds_off(brow, s2);
-    const int arow0 = wm * (16 * IB) + frow + (W + 1);
-    // Fragment addresses of a tap, per pixel row i and kind (fp16 half 0 / half 1 / e4m3 low / high 16 bytes): the tap's swizzled
-    // base, or (zero row - i * 2048) where the tap falls outside the image for this lane's pixel; the row step i * 2048 is the read's
-    // instruction offset.  One wave per SIMD has no partner to hide vector instructions behind: the steps of the fp16 groups (four
-    // 16-cycle MFMAs) have room for two reads and nothing else, so the 6 instructions per row that make these addresses run in the
-    // e4m3 steps (four 32-cycle MFMAs) of the tap BEFORE — row i of the next tap at step 2 IB + i, when this tap's reads of that
-    // row have all been issued.
-    int adr[IB][4];
-    auto row_addresses = [&](int i, int tap) {
-        const int arow = arow0 + (tap / 3 - 1) * W + (tap % 3 - 1);
-        const bool ok = (amask[i] & (1u << tap)) != 0;
-        const int z = zoff - i * 2048;
-        adr[i][0] = ok ? lds_off(arow, fq) : z;
-        adr[i][1] = ok ? lds_off(arow, 4 + fq) : z;
-        adr[i][2] = ok ? APL + lds_off(arow, s1) : z;
-        adr[i][3] = ok ? APL + lds_off(arow, s2) : z;
-    };
-    bf16x8 bh0[JT], bh1[JT];
-    u32x4 wl[JT], wh[JT];
-    u32x4 ring0[4], ring1[4];            // pixel fragments, three steps ahead of their MFMAs (ring1: the e4m3 rows' second half)
-    // entry e of a tap's fragment stream: rows of fp16 half 0 | rows of half 1 | e4m3 rows
-    auto issue = [&](int e) {
-        const int i = e % IB, kind = e / IB, r = e & 3;
-        if (kind < 2) ring0[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][kind] + i * 2048);
-        else {
-            ring0[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][2] + i * 2048);
-            ring1[r] = *reinterpret_cast<const u32x4*>(smem + adr[i][3] + i * 2048);
-        }
-    };
-
-    const int nslab = Cin / CBK;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dma_piece(Bbase, 0, 0, k);
-    load_window(0);
-    int it = 0;
-    for (int sl = 0; sl < nslab; ++sl) {
-        const int c0 = sl * CBK;
-        if (sl > 0) load_window(c0);
-        if (sl > 0) asm volatile("s_barrier" ::: "memory");   // every wave has consumed the previous slab's last fragments
-        store_window();
-        __syncthreads();                                     // window visible; tile 0 of the slab has landed (vmcnt(0))
-        {
-            char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
-            char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dma_piece(Bnxt, 1, c0, k);
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                bh0[j] = *reinterpret_cast<const bf16x8*>(Bcur + bo0 + j * 2048);
-                bh1[j] = *reinterpret_cast<const bf16x8*>(Bcur + bo1 + j * 2048);
-            }
-#pragma unroll
-            for (int i = 0; i < IB; ++i) row_addresses(i, 0);
-            issue(0);
-            issue(1);
-            issue(2);
-        }
-        for (int tap = 0; tap < 9; ++tap, ++it) {
-            char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
-            char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
-            // the tile that goes into this tap's buffer once every wave is done with it
-            const bool ddo = tap < 7 || (tap == 7 && sl + 1 < nslab);
-            const int dtap = tap < 7 ? tap + 2 : 0, dc0 = tap < 7 ? c0 : c0 + CBK;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int e = s + 3;
-                // next tap's addresses of row s - 2 IB (its last read of this tap, the e4m3 entry, went out three steps ago)
-                if (s >= 2 * IB && tap < 8) row_addresses(s - 2 * IB, tap + 1);
-                if (e < NS) issue(e);
-                else if (tap < 8) issue(e - NS);
-                // the e4m3 weight fragments during the fp16 groups: one read every second step
-                if (s < 2 * IB && (s & 1) == 0) {
-                    const int j = s >> 2;
-                    if ((s & 2) == 0) wl[j] = *reinterpret_cast<const u32x4*>(Bcur + bq0 + j * 2048);
-                    else wh[j] = *reinterpret_cast<const u32x4*>(Bcur + bq1 + j * 2048);
-                }
-                if (s == 2 * IB + 1 && tap < 8) {
-                    // the next tap's tile has landed (its DMA was issued one tap ago); every wave holds this tap's weight fragments
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                }
-                // after the barrier: both fp16 weight halves of the next tap (one read per step, the first half first) and the DMA of
-                // the tile after next into the buffer this tap has finished with
-                if (s >= 2 * IB + 1 && s < 2 * IB + 5 && tap < 8) {
-                    const int k = s - (2 * IB + 1);
-                    bh0[k] = *reinterpret_cast<const bf16x8*>(Bnxt + bo0 + k * 2048);
-                    if (ddo) dma_piece(Bcur, dtap, dc0, k);
-                }
-                if (s >= 2 * IB + 4 && s < 2 * IB + 8 && tap < 8) {
-                    const int k = s - (2 * IB + 4);
-                    bh1[k] = *reinterpret_cast<const bf16x8*>(Bnxt + bo1 + k * 2048);
-                }
-                const int i = s % IB, r = s & 3;
-                if (s < IB) {
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh0[j], __builtin_bit_cast(bf16x8, ring0[r]), acc[i][j]);
-                } else if (s < 2 * IB) {
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) acc[i][j] = mma16<PREC_F16>(bh1[j], __builtin_bit_cast(bf16x8, ring0[r]), acc[i][j]);
-                } else {
-                    const u32x4 lo = ring0[r], hi = ring1[r];
-                    const i32x8 x8 = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-#pragma unroll
-                    for (int j = 0; j < JT; ++j) {
-                        const i32x8 w8 = {(int)wl[j][0], (int)wl[j][1], (int)wl[j][2], (int)wl[j][3], (int)wh[j][0], (int)wh[j][1], (int)wh[j][2], (int)wh[j][3]};
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, x8, acc[i][j], 0, 0, 0, wsc[j], 0, xsc);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // coalescing epilogue through LDS, as in conv3x3_window_kernel: [pixel][528 B] rows, whole 512-byte pixel rows to memory
-    constexpr int OP = 528;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            f32x4 v = acc[i][j] + bv;
-            if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
-            char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
-            if (p.y_packed) {
-                uint32_t h01, h23, v8, r8;
-                cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
-                char* slab = row + (nl >> 6) * 256;
-                const int cs = nl & 63;
-                *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);
-                *reinterpret_cast<uint32_t*>(slab + 128 + cs) = v8;
-                *reinterpret_cast<uint32_t*>(slab + 192 + cs) = r8;
-            } else {
-                *reinterpret_cast<f32x4*>(row + nl * 4) = v;
-            }
-        }
-    }
-    __syncthreads();
-    const int col = tid & 31;
-#pragma unroll 8
-    for (int k = 0; k < TBM / 8; ++k) {
-        const int pix = (tid >> 5) + 8 * k;
-        const int m = m0 + pix;
-        if (m < p.M)
-            *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
-    }
-}
+// (Round 2 kept an experimental four-wave form of the split8 kernel here — one wave of 128 x 64 outputs per SIMD, bit-identical,
+// 7-14 % slower in place: DESIGN.md section 4.4d has the measurements.  Removed in round 3 with the rest of the debug surface; it is
+// in the history at 469c692.)
 
 // y = f(sum_ks part[ks] + bias): the second launch of a split-K convolution (fixed summation order)
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, float* __restrict__ y,
-                                                             long long nvec, int Cout, int S, int relu) {
+                                                             long long nvec, int Cout, int S, int relu, uint32_t* __restrict__ y_rec) {
     const long long plane = nvec * 4;
+    uint32_t amax_u = 0u;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
         for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4*>(part + k * plane + i * 4);
         if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % Cout));
-        if (relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
         if (mask != nullptr) {
             const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax_u = max(amax_u, __float_as_uint(v[r]) & 0x7fffffffu);
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
     }
+    if (y_rec != nullptr) range_note(y_rec, amax_u);
 }
 
 // split-K factor of the window kernel: when the map has too few output tiles to fill the chip (small batches), the
@@ -1369,13 +1197,16 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
 
 size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
-    return (size_t)Cout * 9 * Cin * sizeof(uint16_t) + (size_t)Cout * 4;   // the e4m3 plane carries [Cout][4] scale bytes behind it
+    // the e4m3 planes | [Cout][4] scale bytes | [Cout] floats 2^-Ew | { L1 bound, max |bias|, 0, 0 }
+    return (size_t)Cout * 9 * Cin * sizeof(uint16_t) + (size_t)Cout * 8 + 16;
 }
 
-int dasv_conv3x3_pack_weights_x8(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
+int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
     if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0 || Cin % 64 != 0) return DASV_E_SHAPE;
-    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w,
+    hipError_t e = hipMemsetAsync(static_cast<char*>(w_e4m3) + (size_t)Cout * 9 * Cin * 2 + (size_t)Cout * 8, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w, bias,
                        static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin);
     return (int)hipGetLastError();
 }
@@ -1393,7 +1224,8 @@ int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
-                          const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, int force_w4 = 0) {
+                          const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, const uint32_t* x_rec = nullptr,
+                          uint32_t* y_rec = nullptr) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1408,13 +1240,14 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.mel = mel; p.w1 = w1; p.b1 = b1;
     p.part = nullptr; p.ksplit = 1;
     p.x_packed = x_packed; p.y_packed = y_packed;
+    p.x_rec = x_rec; p.y_rec = y_rec;
     if ((x_packed || y_packed) && (mode != 3 || mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
+    if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
     p.row_span = row_span;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
-    static const int force_tile_kernel = getenv("DASV_CONV_TILE_KERNEL") != nullptr ? 1 : 0;   // initialised once, thread-safe
-    if (W <= 80 && (!force_tile_kernel || mel != nullptr || colsum != nullptr || row_span != nullptr)) {
+    if (W <= 80) {
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
         // (a packed output is written by the convolution's own epilogue: no split-K form)
         const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr && !y_packed) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
@@ -1441,18 +1274,6 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             p.ksplit = S;
         }
         const dim3 grid((unsigned)(p.tiles_per_xcd * 8 * p.ksplit)), block(512);
-        // experimental four-wave kernel (see conv3x3_x8w4_kernel): opt-in, packed input, one pass, plain epilogue, maps up to 40 columns
-        static const int env_w4 = getenv("DASV_CONV_W4") != nullptr ? 1 : 0;
-        const bool w4_ok = mode == 3 && x_packed && dbuf && !t192 && W <= 40 && S == 1 && mask == nullptr && colsum == nullptr &&
-                           (unsigned long long)p.M * Cin * 4ull < (1ull << 32);
-        if (force_w4 && !w4_ok) return DASV_E_SHAPE;
-        if (w4_ok && (force_w4 || env_w4)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_x8w4_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(dasv::conv3x3_x8w4_kernel<8>, dim3((unsigned)(p.tiles_per_xcd * 8)), dim3(256), lds, s, p);
-            return (int)hipGetLastError();
-        }
 #define DASV_LAUNCH_WINDOW(SP, DB, CC, NW, ...)                                                                      \
         do {                                                                                                         \
             constexpr int nwn_ = NW;                                                                                 \
@@ -1485,7 +1306,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             const long long nvec = (long long)p.M * Cout / 4;
             const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
             hipLaunchKernelGGL(dasv::conv3x3_splitk_reduce, dim3(blocks), dim3(256), 0, s, p.part, bias, mask, y, nvec, Cout,
-                               p.ksplit, relu);
+                               p.ksplit, relu, y_rec);
         }
         return (int)hipGetLastError();
     }
@@ -1521,13 +1342,13 @@ int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, c
                           H, W, Cin, Cout, relu, stream);
 }
 
-int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
-                                   int y_packed, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
-                                   int relu, dasv_stream_t stream) {
+int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                   const float* bias, void* y, int y_packed, uint32_t* y_range, void* workspace, size_t workspace_bytes,
+                                   int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
     if (W > 80) return DASV_E_SHAPE;
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
                           static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
-                          x_packed ? 1 : 0, y_packed ? 1 : 0);
+                          x_packed ? 1 : 0, y_packed ? 1 : 0, x_range, y_range);
 }
 
 #if DASV_CONV_STAMPS
@@ -1535,13 +1356,6 @@ int dasv_debug_conv_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasv::dasv_conv_stamps), sizeof(unsigned long long) * 64);
 }
 #endif
-
-int dasv_debug_conv3x3_x8_w4_nhwc(const void* x, const void* w_f16, const void* w_e4m3, const float* bias, void* y, int y_packed,
-                                  int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
-    if (W > 40) return DASV_E_SHAPE;
-    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
-                          static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, relu, stream, nullptr, 1, y_packed ? 1 : 0, 1);
-}
 
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                        const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,
@@ -1551,14 +1365,14 @@ int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_h
                           rows, W, Cin, Cout, relu, stream, row_span);
 }
 
-int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
-                                          int y_packed, const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W,
-                                          int Cin, int Cout, int relu, dasv_stream_t stream) {
+int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                          const float* bias, void* y, int y_packed, uint32_t* y_range, const int* row_span, void* workspace,
+                                          size_t workspace_bytes, int rows, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
     if (row_span == nullptr) return DASV_E_NULL;
     if (W > 80) return DASV_E_SHAPE;
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
                           static_cast<float*>(y), workspace, workspace_bytes, 1, rows, W, Cin, Cout, relu, stream, row_span,
-                          x_packed ? 1 : 0, y_packed ? 1 : 0);
+                          x_packed ? 1 : 0, y_packed ? 1 : 0, x_range, y_range);
 }
 
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,

@@ -106,37 +106,64 @@ __device__ __forceinline__ float load_agent(const float* p) {
 
 __host__ __device__ inline int round_up_i(int a, int m) { return (a + m - 1) / m * m; }
 
-// ---- "split8" operand planes (csrc/conv3x3.hip, PREC_X8): fp32 value v = fp16 hi + residual r ------------------------------
+// ---- range records ------------------------------------------------------------------------------------------------------------
+// A RANGE RECORD is two 32-bit words in device memory that travel beside an activation tensor (split8 convolutions, conv3x3.hip):
+//   [0]  bit pattern of max |v| over the tensor, kept with an unsigned atomic maximum of the sign-cleared bits by the kernel that
+//        writes the tensor (a NaN sorts above every number, so one NaN anywhere is recorded as such); zero before that kernel runs;
+//   [1]  for a PACKED tensor: the power-of-two exponent E its planes were made with (they hold v * 2^E), written by its producer.
+// The fp16 / e4m3 operand planes of the split8 mode only have fp16's and e4m3's exponent range; the record is what lets every
+// tensor be scaled into that range by an exact power of two chosen ON THE DEVICE (no host round trip), whatever its magnitude.
+__device__ __forceinline__ int x8_exp_for(uint32_t amax_bits) {   // E with amax * 2^E in [128, 256); 0 for Inf / NaN (they then propagate)
+    const int be = (int)((amax_bits >> 23) & 0xffu);
+    if (be == 255) return 0;
+    const int E = 134 - be;
+    return E > 126 ? 126 : E;
+}
+__device__ __forceinline__ float x8_pow2(int E) { return __uint_as_float((uint32_t)(E + 127) << 23); }   // E in [-126, 127]
+// wave-level maximum of sign-cleared float bits, then one atomic per wave
+__device__ __forceinline__ void range_note(uint32_t* rec, uint32_t m) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(rec, m);
+}
+// relu that keeps a NaN a NaN (v_max_f32 returns the other operand): torch.relu(NaN) is NaN, and a diverging run must show it
+__device__ __forceinline__ float relu_nan(float v) { return !(v <= 0.f) ? v : 0.f; }
+
+// ---- "split8" operand planes (csrc/conv3x3.hip, PREC_X8): scaled value c = v * 2^E = fp16 hi + residual r --------------------
 constexpr int X8_ACT_SHIFT = 12;   // activation residuals are stored as e4m3(r * 2^12)
 typedef float x8_f32x4 __attribute__((ext_vector_type(4)));
 typedef float x8_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 x8_f16x2 __attribute__((ext_vector_type(2)));
-// X8 staging of four fp32 values: fp16 hi (two words), e4m3 of the values, e4m3 of the scaled residuals.
-// v_cvt_pk_fp8_f32 rounds to nearest even and turns |v| >= 480 into NaN (checked: tools/fp8_mfma_check.hip): clamp first.
-__device__ __forceinline__ void cvt4_x8(x8_f32x4 v, float rscale, uint32_t& h01, uint32_t& h23, uint32_t& v8, uint32_t& r8) {
-    // (36 -> 28 vector instructions per call against the first version: one packed fp16 conversion per pair instead of a scalar
-    // one for the residual and a packed one for the store; packed f32 subtract / multiply — this code never runs beside MFMAs;
-    // no zero-initialised destination for the first e4m3 pack)
-    const x8_f32x2 c01 = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
-    const x8_f32x2 c23 = {__builtin_amdgcn_fmed3f(v[2], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[3], -65504.f, 65504.f)};
+// X8 staging of four fp32 values scaled by s = 2^E (E from the tensor's range record: |v| * s < 256): fp16 hi (two words), e4m3 of
+// the scaled values, e4m3 of the scaled residuals.  Nothing is clamped: inside the recorded range nothing can overflow (fp16 holds
+// 65504, e4m3 448; |c| < 256 and |r| * 2^12 <= 256), and a NaN / Inf input stays one (v_cvt_pk_fp8_f32 turns |v| >= 480 into NaN:
+// tools/fp8_mfma_check.hip) — round 2 clamped here with v_med3, which returns a finite value for a NaN operand and so hid
+// diverged activations.  Values below 2^-14 / s lose bits in the fp16 plane (subnormal): they are 2^-22 of the tensor's maximum.
+__device__ __forceinline__ void cvt4_x8(x8_f32x4 v, float s, uint32_t& h01, uint32_t& h23, uint32_t& v8, uint32_t& r8) {
+    const x8_f32x2 ss = {s, s};
+    const x8_f32x2 c01 = x8_f32x2{v[0], v[1]} * ss, c23 = x8_f32x2{v[2], v[3]} * ss;
     const x8_f16x2 p0 = __builtin_convertvector(c01, x8_f16x2), p1 = __builtin_convertvector(c23, x8_f16x2);
-    const x8_f32x2 rs = {rscale, rscale};
+    const x8_f32x2 rs = {(float)(1 << X8_ACT_SHIFT), (float)(1 << X8_ACT_SHIFT)};
     const x8_f32x2 r01 = (c01 - __builtin_convertvector(p0, x8_f32x2)) * rs, r23 = (c23 - __builtin_convertvector(p1, x8_f32x2)) * rs;
     h01 = __builtin_bit_cast(uint32_t, p0);
     h23 = __builtin_bit_cast(uint32_t, p1);
-    const int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c01[1], -448.f, 448.f), (int)h01, false);
-    v8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(c23[1], -448.f, 448.f), a, true);
-    const int b = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r01[1], -448.f, 448.f), (int)h23, false);
-    r8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(r23[1], -448.f, 448.f), b, true);
+    const int a = __builtin_amdgcn_cvt_pk_fp8_f32(c01[0], c01[1], (int)h01, false);
+    v8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c23[0], c23[1], a, true);
+    const int b = __builtin_amdgcn_cvt_pk_fp8_f32(r01[0], r01[1], (int)h23, false);
+    r8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(r23[0], r23[1], b, true);
 }
 
 // A PACKED activation tensor has the geometry of the fp32 NHWC tensor it replaces — [pixels][C] floats, C % 64 == 0 — but every
-// 256-byte slab of 64 channels holds { fp16 hi x 64 | e4m3(v) x 64 | e4m3(r * 2^12) x 64 }: what the split8 convolution would make
-// of the fp32 values while staging its window, made ONCE by the producer (a conv epilogue, conv11, a pool).  The consumer's staging
-// is then a 16-byte copy with the addresses it already uses.  Four consecutive channels n .. n+3 (n % 4 == 0) of pixel `pix`:
-__device__ __forceinline__ void store_x8(float* y, long long pix, int C, int n, x8_f32x4 v) {
+// 256-byte slab of 64 channels holds { fp16(c) x 64 | e4m3(c) x 64 | e4m3(r * 2^12) x 64 } with c = v * 2^E and E in the tensor's
+// range record: what the split8 convolution would make of the fp32 values while staging its window, made ONCE by the producer (a
+// conv epilogue, conv11, a pool).  The consumer's staging is then a 16-byte copy with the addresses it already uses.  Four
+// consecutive channels n .. n+3 (n % 4 == 0) of pixel `pix`:
+__device__ __forceinline__ void store_x8(float* y, long long pix, int C, int n, x8_f32x4 v, float s) {
     uint32_t h01, h23, v8, r8;
-    cvt4_x8(v, (float)(1 << X8_ACT_SHIFT), h01, h23, v8, r8);
+    cvt4_x8(v, s, h01, h23, v8, r8);
     char* slab = reinterpret_cast<char*>(y + (size_t)pix * C + (n & ~63));
     const int cs = n & 63;
     *reinterpret_cast<uint2*>(slab + cs * 2) = make_uint2(h01, h23);

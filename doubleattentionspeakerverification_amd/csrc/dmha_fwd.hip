@@ -609,9 +609,16 @@ static int largest_divisor_leq(int n, int cap) {
     return 1;
 }
 
-// [round_up(B,64)] arrival counters (zero between launches) | [B][round_up(H,4)] head scores
+// Workspace layout: [kCounterSlots] arrival counters (zero between launches) | [B][round_up(H,4)] head scores | long-T scores.
+// The counter region has a FIXED size, so where the counters live does not depend on B: a workspace that served a launch of
+// one batch size can serve any other (callers cache one buffer per stream and reuse it for whatever fits).  With a
+// B-dependent split, the head scores / raw scores written by a small-B launch sat where a later large-B launch expects
+// zeroed counters: no last arriver was ever elected and those rows of `out` stayed uninitialised.  Batches beyond
+// kCounterSlots utterances run as several launches (fwd_impl).
+constexpr int kCounterSlots = 16384;
 static size_t fixed_workspace_bytes(int B, int H) {
-    return (size_t)round_up_i(B, 64) * sizeof(int) + (size_t)B * round_up_i(H, 4) * sizeof(float);
+    const int bc = B < kCounterSlots ? B : kCounterSlots;
+    return (size_t)kCounterSlots * sizeof(int) + (size_t)bc * round_up_i(H, 4) * sizeof(float);
 }
 
 template <typename XT>
@@ -628,12 +635,26 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     if (att != nullptr) {
         if (workspace == nullptr || workspace_bytes < dasv_dmha_workspace_bytes(B, T, H, dh)) return DASV_E_WORKSPACE;
     }
+    if (B > kCounterSlots) {   // one counter slot per utterance of a launch: larger batches go in slices (same stream: in order)
+        for (int b0 = 0; b0 < B; b0 += kCounterSlots) {
+            const int nb = B - b0 < kCounterSlots ? B - b0 : kCounterSlots;
+            const int rc = fwd_impl<XT>(static_cast<const char*>(x) + (size_t)b0 * sb * E::kBytes, query, att,
+                                        keep != nullptr ? keep + (size_t)b0 * H : nullptr, lengths != nullptr ? lengths + b0 : nullptr,
+                                        out != nullptr ? out + (size_t)b0 * dh : nullptr,
+                                        align != nullptr ? align + (size_t)b0 * T * H : nullptr,
+                                        head_w != nullptr ? head_w + (size_t)b0 * H : nullptr, ctx + (size_t)b0 * H * dh,
+                                        ml != nullptr ? ml + (size_t)b0 * H * 2 : nullptr, workspace, workspace_bytes, nb, T, H, dh,
+                                        sb, st, stream, perm_f, seg);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
 
     FwdParams p;
     p.x = x; p.query = query; p.att = att; p.keep = keep; p.lengths = lengths;
     p.out = out; p.align = align; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
     p.counters = static_cast<int*>(workspace);
-    p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)round_up_i(B, 64) * sizeof(int));
+    p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)kCounterSlots * sizeof(int));
     p.sb = sb; p.st = st; p.seg = seg; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.s_glob = nullptr;
@@ -746,10 +767,11 @@ const char* dasv_error_string(int code) {
 
 size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh) {
     if (B <= 0 || H <= 0) return 0;
-    // [round_up(B,64)] arrival counters (must be zero between launches) | [B][round_up(H,4)] head scores
+    // [kCounterSlots] arrival counters (must be zero between launches; fixed size, see fixed_workspace_bytes) | head scores
     // | only for utterances too long for the LDS score row: [B*H][round_up(T,4)] raw scores
     size_t n = dasv::fixed_workspace_bytes(B, H);
-    if (T > 0 && dh > 0 && !dasv::generic_scores_fit_lds(T, H, dh)) n += (size_t)B * H * dasv::round_up_i(T, 4) * sizeof(float);
+    const int bc = B < dasv::kCounterSlots ? B : dasv::kCounterSlots;
+    if (T > 0 && dh > 0 && !dasv::generic_scores_fit_lds(T, H, dh)) n += (size_t)bc * H * dasv::round_up_i(T, 4) * sizeof(float);
     return n;
 }
 

@@ -11,10 +11,14 @@ namespace dasv {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // x [B,H,W] (one channel), w [Cout,1,3,3], y [B,H,W,Cout]
+// x_rec / y_rec: range records (dasv_common.hpp).  y_rec[0] receives max |y|.  pack: y is written PACKED, scaled by 2^E with E from
+// the bound |y| <= amax_x * sum_t |w[c][t]| + |b[c]| (nine taps: the bound is within a few binades of the true maximum); every
+// workgroup holds all Cout channels' weights, so every workgroup derives the same E; block 0 leaves it in y_rec[1].
 __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          int H, int W, int Cout, long long npix, int relu,
-                                                         const int* __restrict__ row_span, int pack) {
+                                                         const int* __restrict__ row_span, int pack,
+                                                         const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec) {
     // A block walks chunks of C1_CHUNK consecutive pixels.  The one-channel input of a chunk (its pixels + W+1 of halo on each
     // side, one contiguous run) is staged in LDS once; every lane then takes its nine taps from LDS.  (Round 1 had each of the
     // Cout/4 lanes of a pixel issue the nine global loads itself: nine load instructions per 16-byte store kept the kernel at
@@ -32,6 +36,32 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(size_t)(q * 4 + c) * 9 + t];
         if (bias != nullptr) bv[c] = bias[q * 4 + c];
     }
+    float sy = 1.f;
+    if (pack) {
+        __shared__ float c1_red[4];
+        const float ax = __uint_as_float(x_rec[0] & 0x7fffffffu);
+        float bnd = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float l1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) l1 += fabsf(wr[c][t]);
+            const float bc = ax * l1 + fabsf(bv[c]);
+            bnd = !(bc <= bnd) ? bc : bnd;          // keeps a NaN
+        }
+        uint32_t bb = __float_as_uint(bnd);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)bb, off); bb = o > bb ? o : bb; }
+        if ((threadIdx.x & 63) == 0) c1_red[threadIdx.x >> 6] = __uint_as_float(bb);
+        __syncthreads();
+        uint32_t m = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t o = __float_as_uint(c1_red[k]); m = o > m ? o : m; }
+        const int Ey = x8_exp_for(__float_as_uint(__uint_as_float(m) * 1.001f));
+        sy = x8_pow2(Ey);
+        if (blockIdx.x == 0 && threadIdx.x == 0) y_rec[1] = (uint32_t)Ey;
+    }
+    uint32_t amax_u = 0u;
     const int halo = W + 1, span = C1_CHUNK + 2 * halo;
     for (long long p0 = (long long)blockIdx.x * C1_CHUNK; p0 < npix; p0 += (long long)gridDim.x * C1_CHUNK) {
         __syncthreads();                             // the previous chunk's readers are done
@@ -65,24 +95,51 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
                     for (int t = 0; t < 9; ++t) o[c] = fmaf(in[t], wr[c][t], o[c]);
                 if (relu) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
+                    for (int c = 0; c < 4; ++c) o[c] = relu_nan(o[c]);
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) amax_u = max(amax_u, __float_as_uint(o[c]) & 0x7fffffffu);
                 // PACKED output for a split8 consumer (dasv_common.hpp).  (Its three small stores per lane are not what the packed
                 // form costs here — a wave-local LDS transpose into 16-byte stores changed nothing, 0.221 vs 0.225 ms: with 36 FMAs and
                 // the 28-instruction conversion per lane the kernel is bound by vector issue at this write rate.)
-                if (pack) store_x8(y, pix, Cout, q * 4, o);
+                if (pack) store_x8(y, pix, Cout, q * 4, o, sy);
                 else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
             }
         }
     }
+    if (y_rec != nullptr) range_note(y_rec, amax_u);
+}
+
+// max |x| over n floats into rec[0] (atomic maximum of the sign-cleared bits; rec zeroed by the caller): the range record of a
+// tensor that no kernel of this library produced (the input features, a caller's activation tensor)
+__global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restrict__ x, long long n, uint32_t* __restrict__ rec) {
+    uint32_t m = 0u;
+    const long long nv = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m = max(m, __float_as_uint(v[c]) & 0x7fffffffu);
+    }
+    if (blockIdx.x == 0 && (long long)threadIdx.x < n - nv * 4) m = max(m, __float_as_uint(x[nv * 4 + threadIdx.x]) & 0x7fffffffu);
+    range_note(rec, m);
 }
 
 // x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = ceil(H/2), Wo = ceil(W/2); windows clipped at the bottom/right edge (ceil_mode)
 // ragged batch (pool_src != null): B == 1, Ho = total output rows; pool_src[ro] = {first input row, 1 if the window has a second row}
+// x_rec / y_rec (optional; both required with pack): the pooled map's range record is its input's — every input element lies in a
+// window, so the maximum is the same (for signed inputs max |y| <= max |x|: still a bound) — and a packed output is scaled by it
 __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int H, int W, int C, int Ho, int Wo, long long nvec,
-                                                              const int* __restrict__ pool_src, int pack) {
+                                                              const int* __restrict__ pool_src, int pack,
+                                                              const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec) {
     const int cq = C >> 2;
+    float sy = 1.f;
+    if (x_rec != nullptr) {
+        const uint32_t xa = x_rec[0];
+        const int Ey = x8_exp_for(xa);
+        sy = x8_pow2(Ey);
+        if (y_rec != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { y_rec[0] = xa; y_rec[1] = (uint32_t)Ey; }
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
         const long long op = i / cq;
@@ -95,10 +152,16 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
         const float* base = x + (((size_t)b * H + h0) * W + w0) * C + q * 4;
         f4 m = *reinterpret_cast<const f4*>(base);
         const bool hw = w0 + 1 < W;
-        if (hw) { const f4 v = *reinterpret_cast<const f4*>(base + C); m = __builtin_elementwise_max(m, v); }
-        if (hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C); m = __builtin_elementwise_max(m, v); }
-        if (hw && hh) { const f4 v = *reinterpret_cast<const f4*>(base + (size_t)W * C + C); m = __builtin_elementwise_max(m, v); }
-        if (pack) store_x8(y, op, C, q * 4, m);
+        // a NaN in the window comes out as NaN, as in F.max_pool2d (v_max_f32 would return the other operand)
+        auto mx = [](f4 a, f4 v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = (v[c] > a[c] || v[c] != v[c]) ? v[c] : a[c];
+            return a;
+        };
+        if (hw) m = mx(m, *reinterpret_cast<const f4*>(base + C));
+        if (hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C));
+        if (hw && hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C + C));
+        if (pack) store_x8(y, op, C, q * 4, m, sy);
         else *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m;
     }
 }
@@ -235,8 +298,9 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __rest
 extern "C" {
 
 static int c1_launch(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cout, int relu,
-                     const int* row_span, dasv_stream_t stream, int pack = 0) {
+                     const int* row_span, dasv_stream_t stream, int pack, const uint32_t* x_range, uint32_t* y_range) {
     if (x == nullptr || w == nullptr || y == nullptr) return DASV_E_NULL;
+    if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;   // a packed output is scaled from the input's range
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     if (pack && Cout % 64 != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
@@ -245,80 +309,77 @@ static int c1_launch(const float* x, const float* w, const float* bias, float* y
     if (blocks > 256 * 16) blocks = 256 * 16;
     const size_t lds = (size_t)(512 + 2 * W + 2) * sizeof(float);
     hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, H, W,
-                       Cout, npix, relu, row_span, pack);
+                       Cout, npix, relu, row_span, pack, x_range, y_range);
     return (int)hipGetLastError();
 }
 
-int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, int B, int H, int W,
-                                      int Cout, int relu, dasv_stream_t stream) {
-    return c1_launch(x, w, bias, static_cast<float*>(y_packed), B, H, W, Cout, relu, nullptr, stream, 1);
+int dasv_range_absmax_f32(const float* x, size_t n, uint32_t* range, dasv_stream_t stream) {
+    if (x == nullptr || range == nullptr) return DASV_E_NULL;
+    if (n == 0 || (uintptr_t)x % 16 != 0) return DASV_E_SHAPE;
+    long long blocks = (long long)((n / 4 + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dasv::range_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, range);
+    return (int)hipGetLastError();
 }
 
-int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
-                                   int Cout, int relu, dasv_stream_t stream) {
-    return c1_launch(x, w, bias, y, B, H, W, Cout, relu, nullptr, stream);
+int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
+                                      uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, static_cast<float*>(y_packed), B, H, W, Cout, relu, nullptr, stream, 1, x_range, y_range);
 }
 
-int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, const int* row_span,
-                                          int rows, int W, int Cout, int relu, dasv_stream_t stream) {
+int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, uint32_t* y_range, int B, int H,
+                                   int W, int Cout, int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, y, B, H, W, Cout, relu, nullptr, stream, 0, nullptr, y_range);
+}
+
+int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, uint32_t* y_range,
+                                          const int* row_span, int rows, int W, int Cout, int relu, dasv_stream_t stream) {
     if (row_span == nullptr) return DASV_E_NULL;
-    return c1_launch(x, w, bias, y, 1, rows, W, Cout, relu, row_span, stream);
+    return c1_launch(x, w, bias, y, 1, rows, W, Cout, relu, row_span, stream, 0, nullptr, y_range);
 }
 
-int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, const int* row_span,
-                                             int rows, int W, int Cout, int relu, dasv_stream_t stream) {
+int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias,
+                                             void* y_packed, uint32_t* y_range, const int* row_span, int rows, int W, int Cout,
+                                             int relu, dasv_stream_t stream) {
     if (row_span == nullptr) return DASV_E_NULL;
-    return c1_launch(x, w, bias, static_cast<float*>(y_packed), 1, rows, W, Cout, relu, row_span, stream, 1);
+    return c1_launch(x, w, bias, static_cast<float*>(y_packed), 1, rows, W, Cout, relu, row_span, stream, 1, x_range, y_range);
 }
 
-int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream) {
+static int pool_launch(const float* x, float* y, const int* pool_src, int B, int H, int Ho, int W, int C, int pack,
+                       const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream) {
     if (x == nullptr || y == nullptr) return DASV_E_NULL;
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;
+    if (B <= 0 || H <= 0 || Ho <= 0 || W <= 0 || C <= 0 || C % (pack ? 64 : 4) != 0) return DASV_E_SHAPE;
+    const int Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo,
-                       nvec, static_cast<const int*>(nullptr), 0);
+                       nvec, pool_src, pack, x_range, y_range);
     return (int)hipGetLastError();
 }
 
-int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, void* y_packed, int B, int H, int W, int C, dasv_stream_t stream) {
-    if (x == nullptr || y_packed == nullptr) return DASV_E_NULL;
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 64 != 0) return DASV_E_SHAPE;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const long long nvec = (long long)B * Ho * Wo * (C / 4);
-    long long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       static_cast<float*>(y_packed), H, W, C, Ho, Wo, nvec, static_cast<const int*>(nullptr), 1);
-    return (int)hipGetLastError();
+int dasv_maxpool2x2_ceil_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, int B, int H, int W, int C,
+                              dasv_stream_t stream) {
+    return pool_launch(x, y, nullptr, B, H, (H + 1) / 2, W, C, 0, x_range, y_range, stream);
 }
 
-int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_src, int rows_in, int rows_out, int W, int C,
-                                     dasv_stream_t stream) {
-    if (x == nullptr || y == nullptr || pool_src == nullptr) return DASV_E_NULL;
-    if (rows_in <= 0 || rows_out <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
-    const int Wo = (W + 1) / 2;
-    const long long nvec = (long long)rows_out * Wo * (C / 4);
-    long long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, rows_in, W, C,
-                       rows_out, Wo, nvec, pool_src, 0);
-    return (int)hipGetLastError();
+int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,
+                                 int C, dasv_stream_t stream) {
+    return pool_launch(x, static_cast<float*>(y_packed), nullptr, B, H, (H + 1) / 2, W, C, 1, x_range, y_range, stream);
 }
 
-int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, void* y_packed, const int* pool_src, int rows_in, int rows_out, int W, int C,
-                                        dasv_stream_t stream) {
-    if (x == nullptr || y_packed == nullptr || pool_src == nullptr) return DASV_E_NULL;
-    if (rows_in <= 0 || rows_out <= 0 || W <= 0 || C <= 0 || C % 64 != 0) return DASV_E_SHAPE;
-    const int Wo = (W + 1) / 2;
-    const long long nvec = (long long)rows_out * Wo * (C / 4);
-    long long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       static_cast<float*>(y_packed), rows_in, W, C, rows_out, Wo, nvec, pool_src, 1);
-    return (int)hipGetLastError();
+int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, const int* pool_src,
+                                     int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (pool_src == nullptr) return DASV_E_NULL;
+    return pool_launch(x, y, pool_src, 1, rows_in, rows_out, W, C, 0, x_range, y_range, stream);
+}
+
+int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range,
+                                        const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (pool_src == nullptr) return DASV_E_NULL;
+    return pool_launch(x, static_cast<float*>(y_packed), pool_src, 1, rows_in, rows_out, W, C, 1, x_range, y_range, stream);
 }
 
 static long long maxpool_bwd_blocks(int B, int H, int W, int C) {

@@ -451,7 +451,13 @@ class DoubleMHA(nn.Module):
         the frame vectors [B,T',C*F'] of CNNs.py:88-89 are never materialised.  Returns out, or (out, alignment)."""
         if self.training and head_keep is None:
             head_keep = self.headsAttention.draw_head_keep(h4.size(0), self.heads_number, h4.device)
-        out, align = _PoolNHWCFn.apply(h4, self.utteranceAttention.query, self.headsAttention.att, head_keep, lengths, want_align)
+        try:
+            out, align = _PoolNHWCFn.apply(h4, self.utteranceAttention.query, self.headsAttention.att, head_keep, lengths, want_align)
+        except _lib.DasvError as e:
+            if e.code != -2:   # DASV_E_SHAPE: maps too long for the in-place kernel's LDS score rows (no shape-agnostic NHWC form)
+                raise
+            frames = h4.permute(0, 2, 1, 3).reshape(h4.size(0), h4.size(2), h4.size(1) * h4.size(3))
+            out, align, _, _ = self._run(frames, head_keep, lengths, want_align)   # any length pools, like the reference
         if want_align:
             self.utteranceAttention.alignment = align
             return out, align

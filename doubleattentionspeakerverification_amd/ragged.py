@@ -65,24 +65,30 @@ def ragged_tables(lengths, levels, device):
     return spans, pools, lens
 
 
-def _conv_ragged(x, conv, packed, mode, span, x_packed=False, y_packed=False):
+def _conv_ragged(x, conv, packed, mode, span, x_packed=False, y_packed=False, x_rec=None, y_rec=None):
     """x [rows, W, Cin] NHWC fp32 -> relu(conv3x3(x) + bias) [rows, W, Cout] with utterance borders from `span`.
-    x_packed / y_packed (split8 only): the tensors are PACKED activations (conv.conv3x3_x8)."""
+    x_packed / y_packed (split8 only): the tensors are PACKED activations (conv.conv3x3_x8).
+    x_rec / y_rec (split8): range records of x and y (conv.new_ranges)."""
     lib = _lib.load()
     rows, W, cin = x.shape
     cout = conv.out_channels
-    hi, lo = packed.get(conv.weight, mode)
+    hi, lo = packed.get(conv.weight, mode, conv.bias)
     y = torch.empty((rows, W, cout), dtype=torch.float32, device=x.device)
     nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(1, rows, W, cin, cout)
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-    if x_packed or y_packed:
-        if mode != "split8":
-            raise RuntimeError("packed activations exist in the split8 mode only")
+    if (x_packed or y_packed) and mode != "split8":
+        raise RuntimeError("packed activations exist in the split8 mode only")
+    if mode == "split8":
+        if x_rec is None:
+            if x_packed:
+                raise RuntimeError("a packed input needs the range record its producer filled")
+            x_rec = _conv.range_of(x)
         with torch.cuda.device(x.device):
             rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(
-                x.data_ptr(), int(x_packed), hi.data_ptr(), lo.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
-                y.data_ptr(), int(y_packed), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin, cout, 1,
-                torch.cuda.current_stream(x.device).cuda_stream)
+                x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                None if conv.bias is None else conv.bias.detach().data_ptr(), y.data_ptr(), int(y_packed),
+                None if y_rec is None else y_rec.data_ptr(), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin,
+                cout, 1, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_x8_nhwc")
         return y
     with torch.cuda.device(x.device):
@@ -131,6 +137,14 @@ def front_end_ragged(front, utterances, mode=None):
     # of the chain wants split-K (groups of utterances that fill the chip; a packed output has no split-K form)
     chain = mode == "split8" and getattr(front, "packed_activations", False) and _packed_chain_ok(front, x.shape[0], W, pools)
     h, h_packed = None, False
+    # split8: one range record per tensor of the pass (conv.new_ranges; CNNs._forward_map_packed)
+    x8 = mode == "split8"
+    recs = iter(_conv.new_ranges(dev, 2 + 3 * front.n_blocks)) if x8 else None
+    rh = None
+    if x8:
+        rx = next(recs)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), stream), "dasv_range_absmax_f32")
     for blk in range(1, front.n_blocks + 1):
         span = spans[blk - 1]
         for name in ("conv%d1" % blk, "conv%d2" % blk):
@@ -139,11 +153,15 @@ def front_end_ragged(front, utterances, mode=None):
             if conv.in_channels == 1:
                 rows = x.shape[0]
                 h = torch.empty((rows, W, conv.out_channels), dtype=torch.float32, device=dev)
-                fn = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc if chain else lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc
+                rh = next(recs) if x8 else None
+                wp, bp = conv.weight.detach().contiguous().data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr()
                 with torch.cuda.device(dev):
-                    rc = fn(x.data_ptr(), conv.weight.detach().contiguous().data_ptr(),
-                            None if conv.bias is None else conv.bias.detach().data_ptr(), h.data_ptr(), span.data_ptr(), rows, W,
-                            conv.out_channels, 1, stream)
+                    if chain:
+                        rc = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(x.data_ptr(), rx.data_ptr(), wp, bp, h.data_ptr(), rh.data_ptr(),
+                                                                          span.data_ptr(), rows, W, conv.out_channels, 1, stream)
+                    else:
+                        rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(x.data_ptr(), wp, bp, h.data_ptr(), None if rh is None else rh.data_ptr(),
+                                                                       span.data_ptr(), rows, W, conv.out_channels, 1, stream)
                 _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
                 h_packed = chain
             elif chain:
@@ -152,8 +170,9 @@ def front_end_ragged(front, utterances, mode=None):
                 if packed is None:
                     packed = front._packed[key] = _conv.PackedConvWeights()
                 # convX1 hands convX2 a packed tensor; convX2's output goes to the pool in fp32 (the maximum needs all its bits)
-                h = _conv_ragged(h, conv, packed, mode, span, x_packed=h_packed, y_packed=first)
-                h_packed = first
+                ry = next(recs)
+                h = _conv_ragged(h, conv, packed, mode, span, x_packed=h_packed, y_packed=first, x_rec=rh, y_rec=ry)
+                h_packed, rh = first, ry
             else:
                 if not _conv.supported(conv.in_channels, conv.out_channels):
                     raise RuntimeError("ragged front-end: layer %s (%d -> %d channels) is outside the HIP kernel's shapes"
@@ -162,16 +181,20 @@ def front_end_ragged(front, utterances, mode=None):
                 packed = front._packed.get(key)
                 if packed is None:
                     packed = front._packed[key] = _conv.PackedConvWeights()
-                h = _conv_ragged(h, conv, packed, mode, span)
+                ry = next(recs) if x8 else None
+                h = _conv_ragged(h, conv, packed, mode, span, x_rec=rh, y_rec=ry)
+                rh = ry
         rows_in, rows_out = h.shape[0], pools[blk - 1].shape[0]
         Wo = (W + 1) // 2
         y = torch.empty((rows_out, Wo, h.shape[2]), dtype=torch.float32, device=dev)
         pack_out = chain and blk < front.n_blocks          # the last pool feeds the pooling layer: fp32
         fn = lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc if pack_out else lib.dasv_maxpool2x2_ceil_ragged_nhwc
+        ry = next(recs) if (x8 and rh is not None) else None
         with torch.cuda.device(dev):
-            rc = fn(h.data_ptr(), y.data_ptr(), pools[blk - 1].data_ptr(), rows_in, rows_out, W, h.shape[2], stream)
+            rc = fn(h.data_ptr(), None if ry is None else rh.data_ptr(), y.data_ptr(), None if ry is None else ry.data_ptr(),
+                    pools[blk - 1].data_ptr(), rows_in, rows_out, W, h.shape[2], stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_ragged_nhwc")
-        h, W, h_packed = y, Wo, pack_out
+        h, W, h_packed, rh = y, Wo, pack_out, ry
     # [rows, F', C] -> [rows, C*F'] with feature = c*F' + f (CNNs.py:49-50 / 88-89)
     frames = h.permute(0, 2, 1).reshape(h.shape[0], h.shape[2] * h.shape[1])
     return frames, list(lens[-1])

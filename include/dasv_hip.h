@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DASV_ABI_VERSION 1
+#define DASV_ABI_VERSION 2
 
 #define DASV_OK            0
 #define DASV_E_NULL       -1  /* a required pointer is NULL */
@@ -67,7 +67,10 @@ const char* dasv_error_string(int code);
  *   ml       [B,H,2] f32   softmax statistics saved for backward: (max, sum) of the
  *                          log2-domain scores; NULL => skipped
  *   workspace              dasv_dmha_workspace_bytes() bytes, zeroed ONCE by
- *                          dasv_dmha_workspace_init(); the kernel leaves it zeroed.
+ *                          dasv_dmha_workspace_init(); every launch leaves its arrival
+ *                          counters zeroed, and they sit in a region of FIXED size at
+ *                          the start, so one buffer may serve launches of different
+ *                          B / T / H (any shape whose dasv_dmha_workspace_bytes() fits).
  *                          Not shareable between launches that may overlap in time.
  *
  * Score scale is 1/sqrt(H) (poolings.py:75: d_k = query.size(-1)).
@@ -144,14 +147,28 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
 size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin);
 int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, dasv_stream_t stream);
 int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
-/*       mode 3: fp32-grade on fewer matrix-pipe cycles, FORWARD / activations only, maps up to 80 columns: v = hi + r with
- *               hi = fp16(v); hi*hi on the fp16 MFMA, both cross terms hi*r' + r*hi' on one block-scaled e4m3 MFMA per 64
- *               input channels (residuals are 2^-11 of the value, 4 significant bits suffice).  ~1e-5 of the output scale
- *               against a float64 convolution for activations between 0.01 and 100 (mode 0: 5e-6, mode 2: 3e-4).  w_hi =
- *               the fp16 plane and w_lo = the e4m3 plane (+ per-channel scale bytes) of dasv_conv3x3_pack_weights_x8;
- *               w_lo holds dasv_conv3x3_packed_weight_bytes_x8(Cout, Cin) bytes.  Gradients go through mode 0. */
+/*       mode 3 ("split8"): fp32-grade on fewer matrix-pipe cycles, FORWARD / activations only, maps up to 80 columns: the
+ *               operand c = v * 2^E is split c = hi + r with hi = fp16(c); hi*hi on the fp16 MFMA, both cross terms hi*r' + r*hi'
+ *               on one block-scaled e4m3 MFMA per 64 input channels (residuals are 2^-11 of the value, 4 significant bits
+ *               suffice).  ~1e-5 of the output scale against a float64 convolution (mode 0: 5e-6, mode 2: 3e-4) at ANY
+ *               magnitude of activations and weights: E is an exact power of two per tensor, taken on the device from the
+ *               tensor's RANGE RECORD (below), weights are scaled per output channel when they are packed, and the epilogue
+ *               undoes both.  Inf / NaN propagate.  Mode 3 is reached through dasv_conv3x3_bias_relu_x8_nhwc (the
+ *               mode argument of the generic entry points returns DASV_E_NULL for it: they carry no range records).
+ *               w_hi = the fp16 plane and w_lo = the e4m3 planes + scales of dasv_conv3x3_pack_weights_x8 (bias: the layer's
+ *               bias or NULL — its maximum bounds the layer's output); w_lo holds dasv_conv3x3_packed_weight_bytes_x8(Cout, Cin)
+ *               bytes.  Gradients go through mode 0. */
 size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin);
-int dasv_conv3x3_pack_weights_x8(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
+int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16, void* w_e4m3, int Cout, int Cin,
+                                 dasv_stream_t stream);
+
+/* RANGE RECORDS.  A range record is uint32_t[2] in device memory beside an activation tensor: [0] = the bit pattern of
+ * max |v| over the tensor (kept by the kernel that writes the tensor with an atomic maximum; the caller zeroes the record
+ * before that kernel runs; a NaN anywhere is recorded as a NaN), [1] = for a PACKED tensor the exponent E it was packed with.
+ * Every forward kernel below that writes an activation tensor takes an optional `y_range`; the split8 convolution requires
+ * the `x_range` of its input.  For a tensor this library did not produce (the input features, a caller's own activations):
+ * dasv_range_absmax_f32 fills a (zeroed) record from n floats (x 16-byte aligned).  No host synchronisation anywhere. */
+int dasv_range_absmax_f32(const float* x, size_t n, uint32_t* range, dasv_stream_t stream);
 int dasv_conv3x3_bias_relu_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                 int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
 /* Same with a caller-provided workspace of dasv_conv3x3_workspace_bytes() bytes: when the map has too few output tiles to
@@ -191,11 +208,13 @@ int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw,
 
 /* conv3x3 with ONE input channel (+ bias + ReLU): x [B,H,W] fp32 -> y [B,H,W,Cout] NHWC fp32.  Replaces
  * `F.relu(self.conv11(x))` (CNNs.py:38 / 72); w is the torch weight [Cout,1,3,3].  Cout % 4 == 0, (Cout/4) | 256. */
-int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
-                                   int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_nhwc(const float* x, const float* w, const float* bias, float* y, uint32_t* y_range, int B, int H,
+                                   int W, int Cout, int relu, dasv_stream_t stream);
 /* 2x2 stride-2 ceil-mode max-pool on NHWC fp32: x [B,H,W,C] -> y [B,ceil(H/2),ceil(W/2),C].  Replaces
  * `F.max_pool2d(x, 2, stride=2, ceil_mode=True)` (CNNs.py:40,44,48 / 74,78,82,86).  C % 4 == 0. */
-int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int C, dasv_stream_t stream);
+/* x_range / y_range (optional, together): the pooled map's range record is its input's (every input lies in a window). */
+int dasv_maxpool2x2_ceil_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, int B, int H, int W, int C,
+                              dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Ragged batches (inference): utterances of DIFFERENT lengths processed as one tall image.  The reference can only run
@@ -210,20 +229,19 @@ int dasv_maxpool2x2_ceil_nhwc(const float* x, float* y, int B, int H, int W, int
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                        const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,
                                        int Cout, int relu, dasv_stream_t stream);
-int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, const int* row_span,
-                                          int rows, int W, int Cout, int relu, dasv_stream_t stream);
-int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, float* y, const int* pool_src, int rows_in, int rows_out, int W, int C,
-                                     dasv_stream_t stream);
-/* The same three on PACKED activations (split8 mode, see dasv_conv3x3_bias_relu_x8_nhwc): the producer writes each 64-channel
- * slab as { fp16 x 64 | e4m3(v) x 64 | e4m3(r * 2^12) x 64 }, the consumer's staging becomes a copy.  Results are those of the
- * fp32 ragged chain bit for bit when no launch of the chain wants split-K (dasv_conv3x3_workspace_bytes(1, rows, ...) == 0). */
-int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
-                                          int y_packed, const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W,
-                                          int Cin, int Cout, int relu, dasv_stream_t stream);
-int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, const int* row_span,
-                                             int rows, int W, int Cout, int relu, dasv_stream_t stream);
-int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, void* y_packed, const int* pool_src, int rows_in, int rows_out, int W, int C,
-                                        dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_ragged_nhwc(const float* x, const float* w, const float* bias, float* y, uint32_t* y_range,
+                                          const int* row_span, int rows, int W, int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_ragged_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, const int* pool_src,
+                                     int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
+/* The same three in the split8 mode, optionally on PACKED activations (see dasv_conv3x3_bias_relu_x8_nhwc). */
+int dasv_conv3x3_bias_relu_ragged_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                          const float* bias, void* y, int y_packed, uint32_t* y_range, const int* row_span, void* workspace,
+                                          size_t workspace_bytes, int rows, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias,
+                                             void* y_packed, uint32_t* y_range, const int* row_span, int rows, int W, int Cout,
+                                             int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range,
+                                        const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
 
 /* Backward of the max-pool above: gx [B,H,W,C] (OVERWRITTEN) from x [B,H,W,C] and gy [B,ceil(H/2),ceil(W/2),C]; the
  * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d
@@ -244,20 +262,26 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * PACKED activations (inference chains of mode-3 convolutions).  A packed tensor has the geometry of the fp32 NHWC tensor it
- * replaces — [B,H,W,C] floats, C % 64 == 0 — but every 256-byte slab of 64 channels holds { fp16 hi x 64 | e4m3(v) x 64 |
- * e4m3((v - hi) * 2^12) x 64 }: what the mode-3 convolution makes of fp32 values while it stages its window, made once by
- * the producer.  Results are bit-identical to the fp32 chain (same conversion arithmetic); the consumer's staging becomes a
- * copy.  Producers: the mode-3 convolution itself (y_packed), conv11 (dasv_conv3x3_c1_bias_relu_x8_nhwc), the max-pool
- * (dasv_maxpool2x2_ceil_x8_nhwc: fp32 in, packed out).  Consumer: dasv_conv3x3_bias_relu_x8_nhwc with x_packed.
- * Replaces nothing new in the reference: these are the calls above with one conversion moved (CNNs.py:72-86 in eval mode).
+ * The split8 convolution (mode 3 above) and PACKED activations (inference chains of split8 convolutions).
+ *   dasv_conv3x3_bias_relu_x8_nhwc: y = relu?(conv(x) + bias).  x_range REQUIRED (its [0] for an fp32 x, its [1] for a packed x);
+ *   y_range optional for an fp32 y (receives max |y|), REQUIRED for a packed y.
+ * A packed tensor has the geometry of the fp32 NHWC tensor it replaces — [B,H,W,C] floats, C % 64 == 0 — but every 256-byte
+ * slab of 64 channels holds { fp16(c) x 64 | e4m3(c) x 64 | e4m3((c - hi) * 2^12) x 64 }, c = v * 2^E: what the convolution makes
+ * of fp32 values while it stages its window, made once by the producer, whose record carries E: the consumer's staging becomes
+ * a copy.  E comes from the tensor's maximum where the producer knows it before it writes (the max-pool: its input's
+ * maximum), else from a bound on it (conv11 and the convolution itself: |y| <= max|x| * max_n sum_k |w[n][k]| + max|b|, a few
+ * binades above the true maximum — the fp16 plane has 30 binades).  Producers: this convolution (y_packed), conv11
+ * (dasv_conv3x3_c1_bias_relu_x8_nhwc; x_range = the record of the input features), the max-pool (dasv_maxpool2x2_ceil_x8_nhwc:
+ * fp32 in, packed out).  Replaces nothing new in the reference: these are the calls above with one conversion moved
+ * (CNNs.py:72-86 in eval mode).
  * ------------------------------------------------------------------------ */
-int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const void* w_f16, const void* w_e4m3, const float* bias, void* y,
-                                   int y_packed, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
-                                   int relu, dasv_stream_t stream);
-int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const float* w, const float* bias, void* y_packed, int B, int H, int W,
-                                      int Cout, int relu, dasv_stream_t stream);
-int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, void* y_packed, int B, int H, int W, int C, dasv_stream_t stream);
+int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                   const float* bias, void* y, int y_packed, uint32_t* y_range, void* workspace, size_t workspace_bytes,
+                                   int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
+                                      uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,
+                                 int C, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * The same two launches on the front-end's own NHWC map: x / grad_x are [B, T, F, C] fp32 (what a channels_last
@@ -292,12 +316,6 @@ const char* dasv_debug_last_variant(void);
  * adds per-wave sums into scratch[0..2047] (>= 2048 floats, caller-zeroed).  bench.py times it beside the fused pooling
  * kernel: no kernel that streams x once can be faster than this on the same buffers. */
 int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream);
-/* Experiment (off by default; DASV_CONV_W4=1 routes eligible dasv_conv3x3_bias_relu_x8_nhwc launches to it): the split8
- * convolution on four waves of 128 pixels x 64 channels.  PACKED input, maps of at most 40 columns, no workspace; results are
- * bit-identical to dasv_conv3x3_bias_relu_x8_nhwc(x_packed = 1).  DASV_E_SHAPE where it does not apply. */
-int dasv_debug_conv3x3_x8_w4_nhwc(const void* x, const void* w_f16, const void* w_e4m3, const float* bias, void* y, int y_packed,
-                                  int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

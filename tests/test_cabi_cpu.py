@@ -38,7 +38,7 @@ def test_binding_table_covers_the_header(lib_path):
     from doubleattentionspeakerverification_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.dasv_abi_version() == 1
+    assert lib.dasv_abi_version() == 2
     assert lib.dasv_error_string(-3) == b"workspace missing or too small"
     assert lib.dasv_dmha_workspace_bytes(64, 300, 8, 64) >= 64 * 4
     assert lib.dasv_dmha_bwd_workspace_bytes(64, 300, 8, 64) >= 64 * 512 * 4
@@ -71,11 +71,21 @@ def test_split_k_plan_and_the_packed_chain_gate(lib_path):
         assert lib.dasv_conv3x3_workspace_bytes(1, 64 * H, W, cin, cout) == 0      # a ragged group of the same footprint
     assert lib.dasv_conv3x3_workspace_bytes(1, 19, 10, 1024, 1024) > 0
     assert lib.dasv_conv3x3_workspace_bytes(1, 19, 10, 1024, 1024) % (19 * 10 * 1024 * 4) == 0   # S partial outputs
-    assert lib.dasv_conv3x3_packed_weight_bytes_x8(1024, 1024) == 1024 * 9 * 1024 * 2 + 1024 * 4
-    assert lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(None, 1, None, None, None, None, 0, None, None, 0, 100, 40, 128, 256, 1, None) < 0
-    assert lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(None, None, None, None, None, 100, 80, 128, 1, None) < 0
-    assert lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc(None, None, None, 100, 50, 80, 128, None) < 0
-    assert lib.dasv_debug_conv3x3_x8_w4_nhwc(None, None, None, None, None, 0, 8, 38, 10, 512, 1024, 1, None) < 0
+    # e4m3 planes | [Cout][4] scale bytes | [Cout] per-channel inverse scales | {L1 bound, max |bias|, pad}
+    assert lib.dasv_conv3x3_packed_weight_bytes_x8(1024, 1024) == 1024 * 9 * 1024 * 2 + 1024 * 8 + 16
+    assert lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(None, 1, None, None, None, None, None, 0, None, None, None, 0, 100, 40, 128, 256, 1, None) < 0
+    assert lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(None, None, None, None, None, None, None, 100, 80, 128, 1, None) < 0
+    assert lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc(None, None, None, None, None, 100, 50, 80, 128, None) < 0
+    # the split8 mode scales its operands by range records: without one it refuses (no silent unscaled path), also through the
+    # generic entry points, which carry none
+    assert lib.dasv_conv3x3_bias_relu_x8_nhwc(16, 0, None, 16, 16, None, 16, 0, None, None, 0, 1, 8, 8, 64, 128, 1, None) == -1
+    assert lib.dasv_conv3x3_bias_relu_x8_nhwc(16, 0, 16, 16, 16, None, 16, 1, None, None, 0, 1, 8, 8, 64, 128, 1, None) == -1   # packed y
+    assert lib.dasv_conv3x3_bias_relu_nhwc(3, 16, 16, 16, None, 16, 1, 8, 8, 64, 128, 1, None) == -1
+    assert lib.dasv_conv3x3_c1_bias_relu_x8_nhwc(16, None, 16, None, 16, None, 1, 8, 8, 64, 1, None) == -1
+    assert lib.dasv_maxpool2x2_ceil_x8_nhwc(16, None, 16, None, 1, 8, 8, 64, None) == -1
+    assert lib.dasv_range_absmax_f32(None, 16, None, None) == -1
+    # the pooling workspace: a fixed-size counter region first, so its layout does not depend on the batch size
+    assert lib.dasv_dmha_workspace_bytes(1, 10, 8, 64) - 1 * 8 * 4 == lib.dasv_dmha_workspace_bytes(130, 10, 8, 64) - 130 * 8 * 4 == 16384 * 4
 
 
 def test_kernels_are_built_for_gfx950_only(lib_path):

@@ -407,3 +407,49 @@ def test_nhwc_map_is_pooled_in_place_like_the_transposed_frames(B, T, C, H):
         np.testing.assert_allclose(res["map"][0][b], ref["out"][0], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(res["map"][1][b, :n], ref["align"][0], rtol=0, atol=1e-6)
         assert float(np.abs(res["map"][1][b, n:]).max(initial=0.0)) == 0.0
+
+
+def test_one_cached_workspace_serves_any_sequence_of_batch_sizes():
+    """the arrival counters used to sit in the first round_up(B,64)*4 bytes of the workspace and the head
+    scores / long-T raw scores behind them — at a B-dependent offset — while poolings caches ONE buffer per (device, stream).
+    A small-B launch (and a long-T one, whose raw scores make the buffer large enough to be reused for ever) wrote where a later
+    B > 64 launch expects zeroed counters: no last arriver was elected and rows of `out` came back uninitialised.  The counter
+    region now has a fixed size.  B = 2 with long T, then B = 8, then B = 130, then 200 and 3 again, same stream, each against
+    the oracle."""
+    import oracle
+    pool = _pool()
+    pool.reset_workspaces()
+    H, dh = 4, 16
+    rs = np.random.RandomState(9)
+    q = (rs.standard_normal((dh, H)) * 0.3).astype(np.float32)
+    a = (rs.standard_normal((dh, 1)) * 0.3).astype(np.float32)
+    for B, T in ((2, 45003), (8, 40), (130, 33), (200, 7), (3, 19), (70, 300)):
+        x = rs.standard_normal((B, T, H * dh)).astype(np.float32)
+        out, align, hw, _ = pool.double_mha(torch.from_numpy(x).to(DEV), torch.from_numpy(q).to(DEV), torch.from_numpy(a).to(DEV))
+        ref = oracle.dmha_closed(x, q, a)
+        np.testing.assert_allclose(out.cpu().numpy(), ref["out"], rtol=2e-4, atol=2e-6, err_msg=str((B, T)))
+        np.testing.assert_allclose(hw.cpu().numpy().reshape(B, H), ref["head_w"].reshape(B, H), rtol=1e-4, atol=1e-6)
+    # and the C ABI's own statement of it: the counter region does not depend on B
+    lib = _lib()
+    assert lib.dasv_dmha_workspace_bytes(1, 10, H, dh) - 1 * H * 4 == lib.dasv_dmha_workspace_bytes(130, 10, H, dh) - 130 * H * 4
+
+
+def test_nhwc_map_of_a_very_long_utterance_falls_back_to_the_frames_path():
+    """the in-place NHWC kernel keeps a score row per head in LDS; a map too long for it (here 45,000 pooled
+    frames = two hours of audio) must not raise — pool_map permutes and takes the shape-agnostic path, like the reference,
+    which pools any length (poolings.py:73-80)."""
+    import oracle
+    pool = _pool()
+    B, T, C, F, H = 1, 45000, 256, 5, 16
+    dh = C * F // H
+    rs = np.random.RandomState(3)
+    frames = rs.standard_normal((B, T, C * F)).astype(np.float32)
+    q = (rs.standard_normal((dh, H)) * 0.2).astype(np.float32)
+    a = (rs.standard_normal((dh, 1)) * 0.2).astype(np.float32)
+    h4 = _t(frames).view(B, T, C, F).permute(0, 2, 1, 3).contiguous(memory_format=torch.channels_last)
+    assert pool.nhwc_frames_supported(h4, H)
+    mod = _module(C * F, H, q, a).eval()
+    with torch.no_grad():
+        out = mod.pool_map(h4)
+    ref = oracle.dmha_closed(frames, q, a)
+    np.testing.assert_allclose(out.cpu().numpy(), ref["out"], rtol=2e-4, atol=2e-6)

@@ -225,31 +225,20 @@ def test_hip_conv3x3_bias_relu_vs_fp64_conv(cin, cout, H, W, B):
     assert y8.shape == ref.shape and float((y8 - ref).abs().max()) / scale < 4e-5
     assert float((yb - ref).abs().max()) / scale < 1e-2
     assert float((yh - ref).abs().max()) / scale < 1.25e-3   # fp16 operands: 8x tighter than bf16
-    if cin == 64:   # fp16 mode saturates instead of overflowing: a 1e6 activation gives a finite map
-        xb = x.clone()
+    if cin == 64:   # a 1e6 activation: the fp16 mode saturates instead of overflowing (finite map, stated); split8 scales the
+        xb = x.clone()   # tensor by its recorded maximum and stays fp32-grade (the reference, CNNs.py:72-86, is exact fp32)
         xb[0, 0, 0, 0] = 1e6
+        refb = torch.relu(torch.nn.functional.conv2d(xb.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))
         with torch.no_grad():
             assert torch.isfinite(conv.conv3x3_bias_relu(xb, w, b, None, "fp16")).all()
-            assert torch.isfinite(conv.conv3x3_bias_relu(xb, w, b, None, "split8")).all()   # e4m3 operands are clamped, not NaN
+            y8b = conv.conv3x3_bias_relu(xb, w, b, None, "split8").cpu().double()
+        assert float((y8b - refb).abs().max()) / float(refb.abs().max()) < 4e-5
 
 
-def test_split8_mode_accuracy_over_activation_scales_and_wide_map_fallback():
-    """The fp16 + e4m3 mode keeps fp32-grade accuracy for activations between 0.01 and 100 (fixed 2^12 residual scale) and
-    degrades towards the plain-fp16 figure, never beyond, outside; maps wider than 80 columns run in split mode."""
+def test_split8_wide_map_fallback():
+    """Maps wider than 80 columns run in split mode (the fp16 + e4m3 form exists in the window kernel only).  The accuracy of
+    split8 over activation / weight magnitudes is held to the fp64 convolution in tests/test_split8_gpu.py."""
     from doubleattentionspeakerverification_amd import conv
-    cin, cout, H, W, B = 256, 128, 12, 20, 2
-    w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
-    x0 = torch.relu(torch.from_numpy(rnd(1, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
-    errs = {}
-    for sx in (1e-3, 1e-2, 1.0, 30.0, 100.0, 1e3):
-        x = (x0 * sx).contiguous(memory_format=torch.channels_last)
-        ref = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
-        with torch.no_grad():
-            y = conv._launch(x, *conv.PackedConvWeights().get(w, "split8"), None, cout, "split8", relu=0).cpu().double()
-        errs[sx] = float((y - ref).abs().max() / ref.abs().max())
-    print("split8 error vs activation scale:", errs)
-    assert max(errs[1e-2], errs[1.0], errs[30.0], errs[100.0]) < 4e-5
-    assert max(errs.values()) < 6e-4
     xw = torch.from_numpy(rnd(4, 1, 64, 3, 96)).to(DEV).contiguous(memory_format=torch.channels_last)
     ww = torch.from_numpy(rnd(5, 128, 64, 3, 3, scale=0.05)).to(DEV)
     with torch.no_grad():
@@ -679,7 +668,8 @@ def test_ragged_batch_equals_one_utterance_per_forward():
 
 def test_packed_activation_chain_vgg3l_and_small_kernel_size():
     """The packed chain is generic over the number of blocks and the channel widths: VGG3L (three blocks, F' = 10) and a
-    narrower VGG4L must also reproduce their fp32 chains bit for bit."""
+    narrower VGG4L must also reproduce their fp32 chains (a packed tensor is scaled by a bound on its maximum, an fp32 one by
+    its maximum: the operand planes agree except where values leave e4m3's normal range, far below the 1e-5 of the mode)."""
     from doubleattentionspeakerverification_amd.CNNs import VGG3L, VGG4L
     torch.manual_seed(11)
     mel = torch.randn(32, 200, 80, device=DEV) * 2.0
@@ -691,16 +681,13 @@ def test_packed_activation_chain_vgg3l_and_small_kernel_size():
             b = fe.forward_map(mel)
             fe.packed_activations = True
         assert a.shape == b.shape
-        if used:
-            assert torch.equal(a, b)
-        else:
-            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), used
     assert VGG3L(1024).to(DEV)._packed_chain_ok(80, 32, 200)      # the wide three-block model does take the packed chain here
 
 
-def test_ragged_packed_activation_chain_is_bit_identical():
+def test_ragged_packed_activation_chain_matches_the_fp32_chain():
     """A ragged group big enough to fill the chip without split-K runs the split8 layers on packed activations (ragged.py,
-    the `_x8` ragged entry points): same arithmetic, so the frame vectors must equal the fp32 ragged chain's bit for bit, and a
+    the `_x8` ragged entry points): the frame vectors must equal the fp32 ragged chain's within the mode's accuracy, and a
     few utterances are checked against their own one-utterance forward."""
     from doubleattentionspeakerverification_amd.CNNs import VGG4L
     from doubleattentionspeakerverification_amd import ragged
@@ -716,7 +703,7 @@ def test_ragged_packed_activation_chain_is_bit_identical():
     fe.packed_activations = False
     b, tb = ragged.front_end_ragged(fe, utts)
     fe.packed_activations = True
-    assert ta == tb and torch.equal(a, b)
+    assert ta == tb and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
     off = 0
     with torch.no_grad():
         for i, n in enumerate(ta):
@@ -868,7 +855,7 @@ def test_packed_conv_weights_follow_replicas_and_data_writes():
         alias = w.detach()                                            # same address, shares the version counter
         w_old = w.detach().clone()
         alias.data.mul_(-1.0)                                         # contents change, w._version does not
-        assert pk2.key == (w.data_ptr(), w._version, w.device, False)
+        assert pk2.key[:3] == (w.data_ptr(), w._version, w.device)
         stale = hc.conv3x3_bias_relu(x, w, bias, pk2)                 # documented: `.data` writes need invalidate()
         assert close(stale, w_old)
         pk2.invalidate()
@@ -910,39 +897,11 @@ def test_data_parallel_replicas_see_current_weights():
     assert float((outs[0][1] - outs[1][1]).abs().max()) > 0
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(8, 75, 20, 256, 512), (3, 38, 10, 128, 128), (2, 41, 40, 64, 256)])
-def test_experimental_four_wave_split8_kernel_is_bit_identical(B, H, W, cin, cout):
-    """csrc/conv3x3.hip keeps an off-by-default split8 kernel on four waves per workgroup (measured slower, kept as a starting
-    point): same MFMAs in the same order per output, so fp32 and packed outputs must equal the production kernel's bit for bit —
-    also on a ragged last tile and a partial window group."""
-    from doubleattentionspeakerverification_amd import conv as hc, _lib
-    lib = _lib.load()
-    torch.manual_seed(3)
-    xf = torch.relu(torch.randn(B, cin, 2 * H, 2 * W, device=DEV)).contiguous(memory_format=torch.channels_last)
-    x = hc.maxpool2x2_ceil(xf, pack=True)
-    w = torch.randn(cout, cin, 3, 3, device=DEV) * (2.0 / (9 * cin)) ** 0.5
-    b = torch.randn(cout, device=DEV) * 0.1
-    pk = hc.PackedConvWeights()
-    hi, lo = pk.get(w, "split8")
-    stream = torch.cuda.current_stream().cuda_stream
-    for y_packed in (0, 1):
-        ref = torch.zeros(B, H, W, cout, device=DEV)
-        got = torch.zeros(B, H, W, cout, device=DEV)
-        _lib.check(lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 1, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), ref.data_ptr(), y_packed,
-                                                      None, 0, B, H, W, cin, cout, 1, stream), "x8")
-        _lib.check(lib.dasv_debug_conv3x3_x8_w4_nhwc(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), b.data_ptr(), got.data_ptr(), y_packed,
-                                                     B, H, W, cin, cout, 1, stream), "x8 w4")
-        assert torch.equal(ref.view(torch.int32), got.view(torch.int32))
-    # wider maps are not its business
-    assert lib.dasv_debug_conv3x3_x8_w4_nhwc(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), b.data_ptr(), got.data_ptr(), 0,
-                                             B, H, 80, cin, cout, 1, stream) != 0
-
-
 @pytest.mark.parametrize("B,T", [(24, 300), (64, 150), (2, 61)])
-def test_packed_activation_chain_is_bit_identical_to_the_fp32_chain(B, T):
+def test_packed_activation_chain_matches_the_fp32_chain_and_the_oracle(B, T):
     """Inference in the split8 mode writes the activations between the layers once, in the consumer's operand form (fp16 hi |
-    e4m3 | e4m3 residual per 64-channel slab): same conversion arithmetic, moved from every consumer workgroup to the producer,
-    so the front-end's output must not change by a single bit.  Also the single pieces against their fp32 forms."""
+    e4m3 | e4m3 residual per 64-channel slab, scaled by the exponent in the tensor's range record): the front-end's output must
+    equal the fp32 chain's within the mode's accuracy, and both the CPU oracle's (CNNs.py:68-91).  Also the single pieces."""
     from doubleattentionspeakerverification_amd.CNNs import VGG4L
     from doubleattentionspeakerverification_amd import conv as hc
     torch.manual_seed(7)
@@ -956,19 +915,26 @@ def test_packed_activation_chain_is_bit_identical_to_the_fp32_chain(B, T):
         fe.packed_activations = False
         b = fe.forward_map(mel)
         fe.packed_activations = True
-        assert a.shape == b.shape and torch.equal(a, b)
-        # pieces: packed conv11 -> conv12 == fp32 conv11 -> conv12; pool(pack) -> conv21(packed in / packed out) -> conv22
-        h11p = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias, pack=True)
-        h11 = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias)
-        y_p = hc.conv3x3_x8(h11p, fe.conv12.weight, fe.conv12.bias, None, x_packed=True)
-        y_f = hc.conv3x3_bias_relu(h11, fe.conv12.weight, fe.conv12.bias, None, "split8")
-        assert torch.equal(y_p, y_f)
-        pp, pf = hc.maxpool2x2_ceil(y_f, pack=True), hc.maxpool2x2_ceil(y_f)
-        z_p = hc.conv3x3_x8(hc.conv3x3_x8(pp, fe.conv21.weight, fe.conv21.bias, None, x_packed=True, y_packed=True),
-                            fe.conv22.weight, fe.conv22.bias, None, x_packed=True)
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        nb = min(B, 4)
+        sd = {"front_end." + k: v.detach().cpu() for k, v in fe.state_dict().items()}
+        torch.set_num_threads(8)
+        ref = oracle.vgg_forward(mel[:nb].cpu(), sd, 4)                       # [nb, T', C*F']
+        got = a[:nb].permute(0, 2, 1, 3).reshape(nb, a.size(2), -1).cpu()
+        assert float((got - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
+        # pieces: packed conv11 -> conv12 vs fp32 conv11 -> conv12; pool(pack) -> conv21(packed in / packed out) -> conv22
+        recs = hc.new_ranges(mel.device, 8)
+        h11p = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias, pack=True, y_rec=recs[0])
+        h11 = hc.conv3x3_c1_bias_relu(mel, fe.conv11.weight, fe.conv11.bias, y_rec=recs[1])
+        assert int(recs[0, 0]) == int(recs[1, 0]) == int(h11.abs().max().view(torch.int32))      # both record max |y| exactly
+        assert float(h11.abs().max()) * 2.0 ** int(recs[0, 1]) < 256.0                           # the bound-derived exponent is safe
+        y_p = hc.conv3x3_x8(h11p, fe.conv12.weight, fe.conv12.bias, None, x_packed=True, x_rec=recs[0], y_rec=recs[2])
+        y_f = hc.conv3x3_bias_relu(h11, fe.conv12.weight, fe.conv12.bias, None, "split8", x_rec=recs[1], y_rec=recs[3])
+        assert float((y_p - y_f).abs().max()) <= 2e-5 * float(y_f.abs().max())
+        assert int(recs[3, 0]) == int(y_f.abs().max().view(torch.int32))
+        pp, pf = hc.maxpool2x2_ceil(y_f, pack=True, x_rec=recs[3], y_rec=recs[4]), hc.maxpool2x2_ceil(y_f)
+        z_p = hc.conv3x3_x8(hc.conv3x3_x8(pp, fe.conv21.weight, fe.conv21.bias, None, x_packed=True, y_packed=True, x_rec=recs[4], y_rec=recs[5]),
+                            fe.conv22.weight, fe.conv22.bias, None, x_packed=True, x_rec=recs[5])
         z_f = hc.conv3x3_bias_relu(hc.conv3x3_bias_relu(pf, fe.conv21.weight, fe.conv21.bias, None, "split8"),
                                    fe.conv22.weight, fe.conv22.bias, None, "split8")
-        if B >= 16:
-            assert torch.equal(z_p, z_f)
-        else:   # small maps: the fp32 chain divides the channel slabs over workgroups (another summation order)
-            assert float((z_p - z_f).abs().max()) < 2e-5 * float(z_f.abs().max())
+        assert float((z_p - z_f).abs().max()) < 2e-5 * float(z_f.abs().max())

@@ -1,0 +1,223 @@
+"""The default forward mode of the convolutions ("split8": fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip)
+held to a float64 convolution and to the CPU oracle at ANY magnitude of activations and weights, and the paths bench.py times
+held to the oracle directly (not to MIOpen, not to the HIP path's own B=1 runs).
+
+The reference computes these layers in exact fp32 at any range (CNNs.py:72-86); BASELINE.json's bar is embeddings within 1e-3
+relative and cosine scores within 1e-4 of the reference CPU path."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _default_params(fe="VGG4L", ks=1024, heads=32, spk=50):
+    return argparse.Namespace(front_end=fe, kernel_size=ks, pooling_method="DoubleMHA", heads_number=heads, mask_prob=0.3,
+                              embedding_size=400, num_spkrs=spk, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+
+
+def _rel(a, ref):
+    return float((a.double() - ref.double()).abs().max() / ref.double().abs().max())
+
+
+def _conv64(x, w, b=None, relu=False):
+    y = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=1)
+    return torch.relu(y) if relu else y
+
+
+def test_split8_is_fp32_grade_at_any_activation_scale():
+    """One tensor scale after the other from 1e-6 to 1e6 (round 2's fixed residual scale was fp32-grade between 0.01 and 100
+    only and saturated beyond 65504): every one within 4e-5 of the float64 convolution's output scale, through the plain
+    entry (the record is measured by a pass over x), with a caller-provided record, and through the packed producers."""
+    from doubleattentionspeakerverification_amd import conv
+    cin, cout, H, W, B = 256, 128, 12, 20, 2
+    w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    x0 = torch.relu(torch.from_numpy(rnd(1, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
+    pk = conv.PackedConvWeights()
+    errs, errs_packed = {}, {}
+    for sx in (1e-6, 1e-3, 1e-2, 1.0, 30.0, 100.0, 1e3, 1e5, 1e6):
+        x = (x0 * sx).contiguous(memory_format=torch.channels_last)
+        ref = _conv64(x, w)
+        with torch.no_grad():
+            y = conv._launch(x, *pk.get(w, "split8"), None, cout, "split8", relu=0)
+            recs = conv.new_ranges(x.device, 3)
+            big = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest").contiguous(memory_format=torch.channels_last)
+            conv.range_of(big)                                              # exercises the measuring kernel on a larger tensor
+            recs[0] = conv.range_of(big)
+            xp = conv.maxpool2x2_ceil(big, pack=True, x_rec=recs[0], y_rec=recs[1])      # == x, packed with an exact scale
+            yp = conv.conv3x3_x8(xp, w, None, pk, x_packed=True, x_rec=recs[1], y_rec=recs[2])   # (+ ReLU)
+        errs[sx] = _rel(y.cpu(), ref)
+        errs_packed[sx] = _rel(yp.cpu(), torch.relu(ref))
+        assert int(recs[1, 0]) == int(x.abs().max().view(torch.int32))
+        assert int(recs[2, 0]) == int(yp.abs().max().view(torch.int32))
+    print("split8 error vs activation scale:", errs, "packed input:", errs_packed)
+    assert max(errs.values()) < 4e-5 and max(errs_packed.values()) < 4e-5
+
+
+def test_split8_heavy_tailed_activations_and_extreme_weights():
+    """Trained networks have heavy-tailed activations (a few channels orders of magnitude above the rest) and weights of any
+    size: log-normal activations spanning ~6 decades with isolated outliers; weight tensors scaled by 1e-6 and 1e4, and with
+    one output channel 1e5 times the others (per-channel weight scales)."""
+    from doubleattentionspeakerverification_amd import conv
+    cin, cout, H, W, B = 128, 256, 21, 10, 3
+    g = np.random.RandomState(5)
+    x = np.exp(g.standard_normal((B, cin, H, W)) * 2.5).astype(np.float32) * (g.rand(B, cin, H, W) > 0.3)
+    x[0, 3, 2, 2] = 3e4
+    x[2, 77, 20, 9] = 8e4
+    x = torch.from_numpy(x.astype(np.float32)).to(DEV).contiguous(memory_format=torch.channels_last)
+    w0 = torch.from_numpy(rnd(12, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    b0 = torch.from_numpy(rnd(13, cout, scale=0.1)).to(DEV)
+    for tag, w, b in (("unit", w0, b0), ("tiny", w0 * 1e-6, b0 * 1e-6), ("huge", w0 * 1e4, b0 * 1e4)):
+        ref = _conv64(x, w, b, relu=True)
+        with torch.no_grad():
+            y = conv.conv3x3_bias_relu(x, w, b, None, "split8")
+        err = _rel(y.cpu(), ref)
+        print("split8 heavy-tailed activations, %s weights: %.2e of the output scale" % (tag, err))
+        assert err < 4e-5, tag
+    wc = w0.clone()
+    wc[5] *= 1e5
+    wc[9] *= 1e-5
+    ref = _conv64(x, wc, b0, relu=True)
+    with torch.no_grad():
+        y = conv.conv3x3_bias_relu(x, wc, b0, None, "split8").cpu().double()
+    # per channel: each output channel against its OWN scale (a per-tensor bound would hide the small channels)
+    for n in (5, 9, 0, 100):
+        assert float((y[:, n] - ref[:, n]).abs().max()) <= 4e-5 * float(ref[:, n].abs().max()) + 1e-30, n
+
+
+def test_split8_propagates_nan_and_inf_like_the_reference():
+    """the clamps of round 2 turned NaN / Inf activations into +-65504, so a diverged run stopped showing NaNs.
+    Now nothing is clamped: a NaN (or Inf) input reaches every output its 3x3 window touches, through the fp32 path, the packed
+    producers (conv11, pool, the convolution's packed epilogue) and the ReLU / max-pool, as torch does; the other outputs
+    stay correct."""
+    from doubleattentionspeakerverification_amd import conv
+    cin, cout, H, W, B = 64, 128, 9, 8, 2
+    w = torch.from_numpy(rnd(22, cout, cin, 3, 3, scale=0.05)).to(DEV)
+    b = torch.from_numpy(rnd(23, cout, scale=0.1)).to(DEV)
+    x = torch.relu(torch.from_numpy(rnd(21, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
+    for bad in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb[1, 7, 4, 3] = bad
+        ref = torch.relu(torch.nn.functional.conv2d(xb, w, b, padding=1))
+        with torch.no_grad():
+            y = conv.conv3x3_bias_relu(xb, w, b, None, "split8")
+            ys = conv.conv3x3_bias_relu(xb, w, b, None, "split")
+        touched = torch.zeros(B, H, W, dtype=torch.bool, device=DEV)
+        touched[1, 3:6, 2:5] = True
+        for out in (y, ys):
+            nonfinite = ~torch.isfinite(out)
+            assert bool(nonfinite.any(dim=1)[touched].all()), bad        # every window that contains it shows it
+            assert not bool(nonfinite.any(dim=1)[~touched].any())        # and nothing else does
+        assert _rel(torch.where(torch.isfinite(y) & torch.isfinite(ref), y, torch.zeros_like(y)).cpu(),
+                    torch.where(torch.isfinite(y) & torch.isfinite(ref), ref, torch.zeros_like(ref)).cpu()) < 4e-5
+    # the packed chain: NaN in the features -> NaN in the front-end map rows it reaches
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    torch.manual_seed(2)
+    fe = VGG4L(1024).to(DEV).eval()
+    mel = torch.randn(16, 150, 80, device=DEV)
+    mel[3, 70, 40] = float("nan")
+    with torch.no_grad():
+        assert fe._packed_chain_ok(80, 16, 150)
+        m = fe.forward_map(mel)
+    bad_rows = ~torch.isfinite(m).all(dim=(1, 2, 3))
+    assert bool(bad_rows[3]) and int(bad_rows.sum()) == 1
+    # max-pool and the one-channel layer on their own
+    t = torch.randn(1, 64, 6, 6, device=DEV).contiguous(memory_format=torch.channels_last)
+    t[0, 5, 2, 3] = float("nan")
+    pm, pr = conv.maxpool2x2_ceil(t), torch.nn.functional.max_pool2d(t, 2, stride=2, ceil_mode=True)
+    assert torch.equal(torch.isnan(pm), torch.isnan(pr)) and bool(torch.isnan(pm).any())
+
+
+def test_default_model_with_large_activations_vs_oracle():
+    """VERDICT r2 task 1(a): the default model with weights rescaled so that the conv3x / conv4x activations reach 1e3 - 1e5 —
+    where round 2's split8 silently fell to fp16-grade layers and saturated — in the default mode (packed chain at B=16 and
+    the fp32 split-K chain at B=1) against oracle.embedding_forward: <= 1e-3 relative, cosine within 1e-4."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
+    with torch.no_grad():
+        for name, f in (("conv12", 40.0), ("conv22", 40.0), ("conv32", 30.0)):
+            getattr(net.front_end, name).weight.mul_(f)
+            getattr(net.front_end, name).bias.mul_(f)
+        net.fc1.weight.mul_(1e-4)          # keep the dense tail in a sane range (linear: does not change what is tested)
+    x = torch.from_numpy(rnd(7, 16, 300, 80))
+    assert net.front_end.conv_mode == "split8" and net.front_end._packed_chain_ok(80, 16, 300)
+    with torch.no_grad():
+        fmap = net.front_end.forward_map(x.to(DEV))
+        big = float(fmap.abs().max())
+        emb = net.getEmbedding(x.to(DEV)).cpu()
+        emb1 = net.getEmbedding(x[:1].to(DEV)).cpu()           # B=1: unpacked fp32 chain, split-K in the narrow-map layers
+    assert 1e3 < big < 1e6, big
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = oracle.embedding_forward(x, sd, 4, 32)
+    rel, rel1 = _rel(emb, ref), _rel(emb1, ref[:1])
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("default model, front-end activations up to %.3g: embedding rel err %.2e (B=1: %.2e), min cosine %.8f" % (big, rel, rel1, cos))
+    assert rel < 1e-3 and rel1 < 1e-3 and 1 - cos < 1e-4
+
+
+def test_timed_paths_against_the_oracle_default_model():
+    """VERDICT r2 task 2: the paths bench.py times, against the oracle directly — the default model in the default mode at
+    B=16, T=300 (packed activations, no split-K: the chain a [64,300,80] batch takes, model.py:52-59), embed_ragged on
+    lengths {150, 297, 301, 800, 17, 1} and embed_utterances (bucketed) at the default width (train.py:117-133 is one
+    utterance per forward: the oracle runs them one at a time)."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.ragged import embed_ragged
+    from doubleattentionspeakerverification_amd.batching import embed_utterances
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    x = torch.from_numpy(rnd(31, 16, 300, 80))
+    assert net.front_end.conv_mode == "split8" and net.front_end.packed_activations and net.front_end._packed_chain_ok(80, 16, 300)
+    with torch.no_grad():
+        emb = net.getEmbedding(x.to(DEV)).cpu()
+        ref = oracle.embedding_forward(x, sd, 4, 32)
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("default model B=16 T=300 (packed chain) vs oracle: rel %.2e, min cosine %.8f" % (_rel(emb, ref), cos))
+    assert _rel(emb, ref) < 1e-4 and 1 - cos < 1e-5                    # bar: 1e-3 / 1e-4
+    lens = [150, 297, 301, 800, 17, 1]
+    utts = [torch.from_numpy(rnd(100 + i, n, 80)) for i, n in enumerate(lens)]
+    with torch.no_grad():
+        refs = torch.cat([oracle.embedding_forward(u.unsqueeze(0), sd, 4, 32) for u in utts])
+        got = embed_ragged(net, [u.to(DEV) for u in utts]).cpu()
+        bucketed = embed_utterances(net, utts + [utts[0].clone(), utts[2].clone()], max_batch=4)
+    for i in range(len(lens)):
+        assert _rel(got[i], refs[i]) < 1e-4, ("ragged", lens[i])
+        assert _rel(bucketed[i].cpu(), refs[i]) < 1e-4, ("bucketed", lens[i])
+    assert _rel(bucketed[6].cpu(), refs[0]) < 1e-4 and _rel(bucketed[7].cpu(), refs[2]) < 1e-4
+
+
+def test_timed_paths_against_the_oracle_front_ends():
+    """VGG3L/1024 (CNNs.py:34-52) and VGG4L/1024 at T=800 (BASELINE config 5's upper length) in the default mode against
+    oracle.vgg_forward — replaces round 2's comparisons with PyTorch-ROCm/MIOpen in split mode."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG3L, VGG4L
+    torch.set_num_threads(8)
+    torch.manual_seed(9)
+    net = VGG3L(1024).to(DEV).eval()
+    sd = {"front_end." + k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for B, T in ((2, 61), (32, 200)):          # split-K fp32 chain / packed chain
+        x = torch.from_numpy(rnd(81, B, T, 80))
+        with torch.no_grad():
+            assert net.conv_mode == "split8" and net._packed_chain_ok(80, B, T) == (B == 32)
+            y = net(x.to(DEV)).cpu()
+            nb = min(B, 3)
+            ref = oracle.vgg_forward(x[:nb], sd, 3)
+        assert y.shape[1:] == ref.shape[1:] and y.shape[2] == 10240
+        assert _rel(y[:nb], ref) < 5e-5, (B, T)
+    net4 = VGG4L(1024).to(DEV).eval()
+    sd4 = {"front_end." + k: v.detach().cpu() for k, v in net4.state_dict().items()}
+    for B in (1, 8):
+        xl = torch.from_numpy(rnd(82, B, 800, 80))
+        with torch.no_grad():
+            y = net4(xl.to(DEV)).cpu()
+            ref = oracle.vgg_forward(xl[:1], sd4, 4)
+        assert y.shape == (B, 50, 5120) and _rel(y[:1], ref) < 5e-5, B
