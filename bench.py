@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: utterance-embeddings/sec on synthetic [B=64, T=300, 80-mel] batches.
 
-    python bench.py --gpus N --steps K --warmup W [--workload embed|pool|train] [--dtype fp32|bf16]
+    python bench.py --gpus N --steps K --warmup W [--regions R] [--workload embed|pool|train|varlen] [--dtype fp32|bf16]
 
 A step is one pass of the hot path over one batch per GPU, inputs already resident in HBM:
   embed (default)  SpeakerClassifier.getEmbedding (VGG4L/1024 front-end -> fused DoubleMHA -> fc/BN),
@@ -56,18 +56,20 @@ class PoolTimer:
     def __init__(self, poolings):
         self.pairs = []
         self.active = False
-        inner = poolings._launch_fwd
 
-        def timed(x, *a, **k):
-            if not self.active:
-                return inner(x, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(torch.cuda.current_stream(x.device))
-            r = inner(x, *a, **k)
-            e.record(torch.cuda.current_stream(x.device))
-            self.pairs.append((s, e))
-            return r
-        poolings._launch_fwd = timed
+        def wrap(inner):
+            def timed(x, *a, **k):
+                if not self.active:
+                    return inner(x, *a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(torch.cuda.current_stream(x.device))
+                r = inner(x, *a, **k)
+                e.record(torch.cuda.current_stream(x.device))
+                self.pairs.append((s, e))
+                return r
+            return timed
+        poolings._launch_fwd = wrap(poolings._launch_fwd)
+        poolings._launch_fwd_nhwc = wrap(poolings._launch_fwd_nhwc)   # the model's path: the front-end's NHWC map pooled in place
 
     def mean_us(self):
         d = [s.elapsed_time(e) * 1e3 for s, e in self.pairs]
@@ -275,6 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of --steps steps each (every one bracketed by barrier + synchronize); the line reports the "
+                         "MEDIAN region, so ms_per_step x steps is the time of one real region")
     ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train", "varlen"])
     ap.add_argument("--utterances", type=int, default=1024, help="varlen: utterances per rank and step")
     ap.add_argument("--packing", default="ragged", choices=["ragged", "bucket"],
@@ -430,23 +435,33 @@ def main():
             step(first + i)
 
     run_steps(0, args.warmup)
-    barrier()
     timer.active = True
     ctimer.active = True
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(args.warmup, args.steps)
-    ev1.record()
-    barrier()
-    region_ms = ev0.elapsed_time(ev1)
-    elapsed = time.perf_counter() - t0
+    # `--regions` timed regions of exactly `--steps` steps, each bracketed by barrier + synchronize on both sides; per region the
+    # MAX over ranks; the line quotes the MEDIAN region (one real region: ms_per_step x steps is its wall time).  Several regions
+    # because one region of the embedding workload is 0.1 s — too short for a sampler outside the process to see the GPU busy,
+    # and a single region inherits whatever clock state the warm-up left.
+    regions = []
+    first = args.warmup
+    for _ in range(max(1, args.regions)):
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        run_steps(first, args.steps)
+        ev1.record()
+        barrier()
+        el = time.perf_counter() - t0
+        first += args.steps
+        regions.append((el, ev0.elapsed_time(ev1)))
     timer.active = False
     ctimer.active = False
+    els = torch.tensor([r[0] for r in regions], device=dev, dtype=torch.float64)
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        dist.all_reduce(els, op=dist.ReduceOp.MAX)
+    els = [float(v) for v in els.tolist()]
+    mid = sorted(range(len(els)), key=lambda i: els[i])[len(els) // 2]
+    elapsed, region_ms = els[mid], regions[mid][1]
 
     if rank == 0:
         Bp, Tp, Dp, Hp = pool_shape
@@ -514,7 +529,7 @@ def main():
                         "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
                         "traffic": pmc_traffic("embed_conv", args.conv) if args.workload == "embed" else None,
                         "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
-                        "launches_per_step": len(ctimer.rec) // max(1, args.steps),
+                        "launches_per_step": len(ctimer.rec) // max(1, args.steps * len(els)),
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
                         "mfma_util_pmc_percent": mfma_util_pmc()}
@@ -559,8 +574,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if args.workload == "pool" or args.conv in ("split8", "split", "torch") else args.conv)
-                     if compute_dtype == torch.float32 else "bf16",
+            # the arithmetic type of the multiplicands (I/O and accumulation are fp32 everywhere): what the matrix cores multiply
+            "dtype": ("f32" if args.workload == "pool" else
+                      {"split8": "f32-io/f16+e4m3-split", "split": "f32-io/3xbf16-split", "torch": "f32", "fp16": "f32-io/f16",
+                       "bf16": "f32-io/bf16"}[args.conv]) if compute_dtype == torch.float32 else "bf16",
+            "regions": {"count": len(els), "steps_each": args.steps, "elapsed_s": [round(v, 5) for v in els], "quoted": "median"},
+            "dist": {"world_size": (dist.get_world_size() if dist is not None else 1),
+                     "backend": (dist.get_backend() if dist is not None else None)},
             "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
             "config": config, "roofline": roofline, "roofline_pooling": pool_roof, "cpu_baseline": cpu,
         }

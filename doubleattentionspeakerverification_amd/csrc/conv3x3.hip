@@ -496,6 +496,10 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         }
     }
     uint32_t amax_u = 0u;   // max of the sign-cleared bits of the values this lane stores (range record of y)
+    // what the record held when this tile began: only a larger maximum is posted (dasv_common.hpp, range_note_block)
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0u;      // visible behind the first barrier of the loops
+    const uint32_t rec_seen = p.y_rec != nullptr ? range_seen(p.y_rec) : 0xffffffffu;
     auto note4 = [&](const f32x4& v) {
         const uint32_t a = __float_as_uint(v[0]) & 0x7fffffffu, b = __float_as_uint(v[1]) & 0x7fffffffu;
         const uint32_t c = __float_as_uint(v[2]) & 0x7fffffffu, d = __float_as_uint(v[3]) & 0x7fffffffu;
@@ -1074,8 +1078,13 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     }
                 }
             }
+            if (p.y_rec != nullptr) {            // workgroup maximum through one LDS word (joined by the barrier below)
+                amax_u = wave_umax(amax_u);
+                if (lane == 0 && amax_u > rec_seen) atomicMax(&s_amax, amax_u);
+            }
             __syncthreads();
             DASV_STAMP(62);
+            if (p.y_rec != nullptr && tid == 0 && s_amax > rec_seen) atomicMax(p.y_rec, s_amax);
             const int col = tid & 31;            // 16-byte chunk of a pixel's 512-byte row; 16 pixels per pass of the workgroup
 #pragma unroll
             for (int k = 0; k < TBM / 16; ++k) {
@@ -1085,7 +1094,6 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
             }
             DASV_STAMP(63);
-            if (p.y_rec != nullptr) range_note(p.y_rec, amax_u);
             return;
         }
     }
@@ -1127,7 +1135,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         __syncthreads();
         if (tid < 128) p.colsum[(size_t)mt * p.Cout + n0 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     }
-    if (p.y_rec != nullptr) range_note(p.y_rec, amax_u);
+    if (p.y_rec != nullptr) range_note(p.y_rec, amax_u, rec_seen);
 }
 
 // (Round 2 kept an experimental four-wave form of the split8 kernel here — one wave of 128 x 64 outputs per SIMD, bit-identical,
@@ -1140,6 +1148,9 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __rest
                                                              long long nvec, int Cout, int S, int relu, uint32_t* __restrict__ y_rec) {
     const long long plane = nvec * 4;
     uint32_t amax_u = 0u;
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0u;
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
         for (int k = 1; k < S; ++k) v += *reinterpret_cast<const f32x4*>(part + k * plane + i * 4);
@@ -1154,7 +1165,7 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __rest
         for (int r = 0; r < 4; ++r) amax_u = max(amax_u, __float_as_uint(v[r]) & 0x7fffffffu);
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
     }
-    if (y_rec != nullptr) range_note(y_rec, amax_u);
+    if (y_rec != nullptr) range_note_block(y_rec, amax_u, &s_amax);
 }
 
 // split-K factor of the window kernel: when the map has too few output tiles to fill the chip (small batches), the

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dasv {
 
@@ -120,14 +121,39 @@ __device__ __forceinline__ int x8_exp_for(uint32_t amax_bits) {   // E with amax
     return E > 126 ? 126 : E;
 }
 __device__ __forceinline__ float x8_pow2(int E) { return __uint_as_float((uint32_t)(E + 127) << 23); }   // E in [-126, 127]
-// wave-level maximum of sign-cleared float bits, then one atomic per wave
-__device__ __forceinline__ void range_note(uint32_t* rec, uint32_t m) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
-        m = o > m ? o : m;
+// Recording a maximum.  Atomics to ONE address execute one after the other at the memory side (~12 ns each): a launch of 8,000
+// workgroups in which every wave posts its maximum keeps that address busy for most of a millisecond and slows the whole channel
+// (measured: the split8 layers +2 ... +11 %, conv11 +60 %, before this was thinned).  So: reduce inside the wave (DPP), then inside the
+// workgroup through one LDS word, and post to memory only what exceeds the value already there — after the first round of
+// workgroups almost nothing does.
+__device__ __forceinline__ uint32_t wave_umax(uint32_t m) {
+    auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xF, 0xF, true); };
+    m = max(m, dpp(m, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+    m = max(m, dpp(m, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+    m = max(m, dpp(m, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    m = max(m, dpp(m, std::integral_constant<int, 0x140>{}));   // row_mirror
+    m = max(m, (uint32_t)__shfl_xor((int)m, 16));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 32));
+    return m;
+}
+__device__ __forceinline__ uint32_t range_seen(const uint32_t* rec) {   // what the record holds now (L2-served: other CUs' atomics are visible)
+    return __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every thread of the workgroup calls this once, with uniform control flow; `slot` is a __shared__ word that was zeroed behind an
+// earlier barrier.  `seen`: a value read from the record earlier in the launch (range_seen), or 0 to read it now.
+__device__ __forceinline__ void range_note_block(uint32_t* rec, uint32_t m, uint32_t* slot, uint32_t seen = 0u) {
+    m = wave_umax(m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(slot, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t v = *slot;
+        if (v != 0u && v > (seen != 0u ? seen : range_seen(rec))) atomicMax(rec, v);
     }
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(rec, m);
+}
+// the same per wave (kernels whose epilogue has no workgroup barrier)
+__device__ __forceinline__ void range_note(uint32_t* rec, uint32_t m, uint32_t seen) {
+    m = wave_umax(m);
+    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(rec, m);
 }
 // relu that keeps a NaN a NaN (v_max_f32 returns the other operand): torch.relu(NaN) is NaN, and a diverging run must show it
 __device__ __forceinline__ float relu_nan(float v) { return !(v <= 0.f) ? v : 0.f; }

@@ -62,6 +62,8 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         if (blockIdx.x == 0 && threadIdx.x == 0) y_rec[1] = (uint32_t)Ey;
     }
     uint32_t amax_u = 0u;
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0u;      // visible behind the barriers of the chunk loop (every block runs at least one chunk)
     const int halo = W + 1, span = C1_CHUNK + 2 * halo;
     for (long long p0 = (long long)blockIdx.x * C1_CHUNK; p0 < npix; p0 += (long long)gridDim.x * C1_CHUNK) {
         __syncthreads();                             // the previous chunk's readers are done
@@ -107,13 +109,16 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
             }
         }
     }
-    if (y_rec != nullptr) range_note(y_rec, amax_u);
+    if (y_rec != nullptr) range_note_block(y_rec, amax_u, &s_amax);
 }
 
 // max |x| over n floats into rec[0] (atomic maximum of the sign-cleared bits; rec zeroed by the caller): the range record of a
 // tensor that no kernel of this library produced (the input features, a caller's activation tensor)
 __global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restrict__ x, long long n, uint32_t* __restrict__ rec) {
     uint32_t m = 0u;
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0u;
+    __syncthreads();
     const long long nv = n >> 2, stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const f4 v = *reinterpret_cast<const f4*>(x + i * 4);
@@ -121,7 +126,7 @@ __global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restri
         for (int c = 0; c < 4; ++c) m = max(m, __float_as_uint(v[c]) & 0x7fffffffu);
     }
     if (blockIdx.x == 0 && (long long)threadIdx.x < n - nv * 4) m = max(m, __float_as_uint(x[nv * 4 + threadIdx.x]) & 0x7fffffffu);
-    range_note(rec, m);
+    range_note_block(rec, m, &s_amax);
 }
 
 // x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = ceil(H/2), Wo = ceil(W/2); windows clipped at the bottom/right edge (ceil_mode)
@@ -318,7 +323,7 @@ int dasv_range_absmax_f32(const float* x, size_t n, uint32_t* range, dasv_stream
     if (n == 0 || (uintptr_t)x % 16 != 0) return DASV_E_SHAPE;
     long long blocks = (long long)((n / 4 + 255) / 256);
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(dasv::range_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, range);
     return (int)hipGetLastError();
 }

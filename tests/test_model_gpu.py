@@ -471,9 +471,10 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     orig_conv, orig_pool = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd
     cap = {}
 
-    def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, link_in=None, link_out=None, fuse=True):
+    def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, link_in=None, link_out=None, x_rec=None,
+                  y_rec=None, fuse=True):
         y = orig_conv(xx, w, b, packed, mode, premasked and fuse, mask_in and fuse, link_in if fuse else None,
-                      link_out if fuse else None)
+                      link_out if fuse else None, x_rec, y_rec)
         name = [k for k, v in net.named_parameters() if v is w][0].split(".")[0]
         cap[name] = dict(x=xx.detach(), y=y.detach(), premasked=premasked and fuse)
         y.register_hook(lambda g, name=name: cap[name].__setitem__("gy", g.detach().clone()))
@@ -483,8 +484,8 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     for mode in ("torch", "fused", "unfused"):
         fuse = mode == "fused"
         monkeypatch.setattr(C, "conv3x3_bias_relu", lambda *a, fuse=fuse, **k: capturing(*a, fuse=fuse, **k))
-        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, fuse=fuse:
-                            orig_pool(t, relu_input and fuse, link_out if fuse else None))
+        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, x_rec=None, y_rec=None, fuse=fuse:
+                            orig_pool(t, relu_input and fuse, link_out if fuse else None, x_rec, y_rec))
         net.conv_mode = "torch" if mode == "torch" else "split"
         net.zero_grad()
         cap.clear()

@@ -120,10 +120,10 @@ def test_split8_propagates_nan_and_inf_like_the_reference():
     from doubleattentionspeakerverification_amd.CNNs import VGG4L
     torch.manual_seed(2)
     fe = VGG4L(1024).to(DEV).eval()
-    mel = torch.randn(16, 150, 80, device=DEV)
+    mel = torch.randn(16, 300, 80, device=DEV)
     mel[3, 70, 40] = float("nan")
     with torch.no_grad():
-        assert fe._packed_chain_ok(80, 16, 150)
+        assert fe._packed_chain_ok(80, 16, 300)
         m = fe.forward_map(mel)
     bad_rows = ~torch.isfinite(m).all(dim=(1, 2, 3))
     assert bool(bad_rows[3]) and int(bad_rows.sum()) == 1
@@ -142,7 +142,7 @@ def test_default_model_with_large_activations_vs_oracle():
     torch.manual_seed(1234)
     net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
     with torch.no_grad():
-        for name, f in (("conv12", 40.0), ("conv22", 40.0), ("conv32", 30.0)):
+        for name, f in (("conv12", 100.0), ("conv22", 100.0), ("conv32", 50.0)):
             getattr(net.front_end, name).weight.mul_(f)
             getattr(net.front_end, name).bias.mul_(f)
         net.fc1.weight.mul_(1e-4)          # keep the dense tail in a sane range (linear: does not change what is tested)
@@ -153,6 +153,7 @@ def test_default_model_with_large_activations_vs_oracle():
         big = float(fmap.abs().max())
         emb = net.getEmbedding(x.to(DEV)).cpu()
         emb1 = net.getEmbedding(x[:1].to(DEV)).cpu()           # B=1: unpacked fp32 chain, split-K in the narrow-map layers
+    print("front-end map maximum %.4g" % big)
     assert 1e3 < big < 1e6, big
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     torch.set_num_threads(8)
