@@ -18,10 +18,14 @@
 //               groups of a wave are merged by xor-shuffles, waves of a unit
 //               through LDS.  Raw scores are parked in LDS so the normalised
 //               alignments are written once, after the unit's (max, sum) is known.
-//   head stage= per-head context vectors go to ctx[B,H,dh] with write-through
-//               (agent scope) stores; a per-utterance arrival counter elects the
-//               last workgroup of each utterance, which re-reads the H vectors
-//               with agent-scope loads and finishes softmax-over-heads + output.
+//   head stage= softmax over heads + weighted sum is an ASSOCIATIVE reduction over heads
+//               (online softmax: (max, sum, weighted vector)), so every workgroup first
+//               folds ITS heads into one partial {M_w, S_w, V_w[dh]} and publishes only
+//               that (write-through, agent scope) beside its heads' scores u_h; a
+//               per-utterance arrival counter elects the last workgroup of each utterance,
+//               which pulls the `arrivals` partials (dh + 4 floats each — not the H context
+//               vectors: 2.6 KB instead of 20 KB for the model's 32 x 160 pooling) with
+//               agent-scope loads and writes out / head_w.  ctx[B,H,dh] is a plain output.
 //               Workgroups of one utterance share blockIdx % 8 (one XCD's L2 under
 //               round-robin placement): speed only, correctness never depends on it.
 #include "dasv_common.hpp"
@@ -41,10 +45,11 @@ struct FwdParams {
     float* out;            // [B,dh]
     float* align;          // [B,T,H] or null
     float* head_w;         // [B,H] or null
-    float* ctx;            // [B,H,dh]
+    float* ctx;            // [B,H,dh] or null
     float* ml;             // [B,H,2] or null
     int* counters;         // [B] arrival counters (zero between launches)
-    float* exch_u;         // [B][round_up(H,4)] head scores <c_h, att>, published beside ctx
+    float* exch_u;         // [B][round_up(H,4)] head scores <c_h, att> (masked heads: -inf), published beside the partials
+    float* exch_p;         // [B][arrivals][4 + round_up(dh,4)] per-workgroup partials {M_w, S_w, 0, 0 | V_w[dh]}
     long long sb, st;      // element strides of x
     long long seg;         // NHWC frames (PERM kernels): element stride between the F' segments of a frame (= channels C)
     int B, T, H, dh;
@@ -73,11 +78,12 @@ struct FwdParams {
 // partial accumulators (already scaled to their wave's max).  The head stage (last arriver only, after every
 // other use) aliases the same bytes from offset 0: [round_up(H,4)] head weights | [ceil(H/8)][dh] partial
 // outputs.  One flag word at the end.
+// ... | [upw][dh] the workgroup's context vectors | [round_up(upw,4)] their head scores (the fold of the workgroup's heads)
 __host__ __device__ inline size_t fwd_lds_stream_floats(int upw, int t_pad, int wpu, int P, int dh) {
-    return (size_t)upw * t_pad + (size_t)upw * wpu * 2 + (size_t)upw * P * dh;
+    return (size_t)upw * t_pad + (size_t)round_up_i(upw * wpu * 2, 4) + (size_t)upw * P * dh + (size_t)upw * dh + (size_t)round_up_i(upw, 4);
 }
 __host__ __device__ inline size_t fwd_lds_head_floats(int H, int dh) {
-    return (size_t)round_up_i(H, 4) + (size_t)((H + 7) / 8) * dh;
+    return (size_t)round_up_i(H, 4) + 16;   // head weights | {M, 1/S}
 }
 __host__ __device__ inline size_t fwd_lds_floats(int upw, int t_pad, int wpu, int P, int H, int dh) {
     const size_t a = fwd_lds_stream_floats(upw, t_pad, wpu, P, dh), b = fwd_lds_head_floats(H, dh);
@@ -92,123 +98,152 @@ __device__ __forceinline__ bool block_to_unit(int arrivals, int B, int& b, int& 
     return b < B;
 }
 
-// ---- head stage: executed by the last-arriving workgroup of utterance b ----------------------
-// Every workgroup has already published its context vector c_h (ctx, write-through) and its head score
-// u_h = <c_h, att> (exch_u, write-through).  The last arriver reads the H scores and the H vectors with
-// agent-scope (L1-bypassing) loads only — ONE round of independent 16-byte loads spread over the whole
-// workgroup — applies the train-time mask, and writes out / head_w.
-// All threads of the workgroup call this (uniform control flow).  `lds` = fwd_lds_head_floats() floats.
+// ---- head stage -------------------------------------------------------------------------------------
+// out = sum_h softmax(u)_h c_h is an online-softmax reduction over heads, so it folds: a workgroup that owns heads h0 .. h0+upw-1
+// publishes  M_w = max u_h,  S_w = sum e^(u_h - M_w),  V_w = sum e^(u_h - M_w) c_h  (a masked head has u = -inf: weight 0), and
+//   out = sum_w e^(M_w - M) V_w / sum_w e^(M_w - M) S_w,   head_w[h] = e^(u_h - M) / S,   M = max_w M_w.
+// All heads masked: every S_w = 0 and out = 0/0 = NaN, as the reference's softmax over -inf scores (poolings.py:47-50).
+__host__ __device__ inline int part_pitch(int dh) { return 4 + round_up_i(dh, 4); }   // floats per partial: {M, S, 0, 0 | V[dh]}
+
+typedef float hs_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_agent4(float* base, int byte_off, int bytes, hs_f4 v) {   // 16-byte write-through (sc1) store
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ hs_f4 load_agent4(const float* base, int byte_off, int bytes) {       // 16-byte L1-bypassing (sc1) load
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    return __builtin_bit_cast(hs_f4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+// Fold and publish, by ONE wave (the caller's wave 0; all 64 lanes active): cbuf [upw][dh] context vectors and ubuf [upw] masked
+// head scores of the workgroup's heads (LDS, behind a barrier).  Everything another workgroup will read is stored write-through
+// by this wave, which then drains its stores — so its lane 0 may take the arrival ticket right after, with no workgroup barrier.
+template <bool VEC4>
+__device__ __forceinline__ void fold_publish(const FwdParams& p, int b, int a, const float* cbuf, const float* ubuf) {
+    const int lane = threadIdx.x & 63, dh = p.dh, upw = p.upw, pitch = part_pitch(dh);
+    float M = -INFINITY;
+    for (int k = 0; k < upw; ++k) M = fmaxf(M, ubuf[k]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float S = 0.f;
+    for (int k = 0; k < upw; ++k) S += fast_exp2((ubuf[k] - Mu) * kLog2e);
+    float* pp = p.exch_p + ((size_t)b * p.arrivals + a) * pitch;
+    if (lane < upw) store_agent(p.exch_u + (size_t)b * round_up_i(p.H, 4) + a * upw + lane, ubuf[lane]);
+    if constexpr (VEC4) {
+        if (lane == 0) store_agent4(pp, 0, pitch * 4, hs_f4{M, S, 0.f, 0.f});
+        for (int q = lane; q < (dh >> 2); q += 64) {
+            hs_f4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < upw; ++k)
+                v += fast_exp2((ubuf[k] - Mu) * kLog2e) * *reinterpret_cast<const hs_f4*>(cbuf + (size_t)k * dh + q * 4);
+            store_agent4(pp, (4 + q * 4) * 4, pitch * 4, v);
+        }
+    } else {
+        if (lane == 0) { store_agent(pp, M); store_agent(pp + 1, S); }
+        for (int d = lane; d < dh; d += 64) {
+            float v = 0.f;
+            for (int k = 0; k < upw; ++k) v = fmaf(fast_exp2((ubuf[k] - Mu) * kLog2e), cbuf[(size_t)k * dh + d], v);
+            store_agent(pp + 4 + d, v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have left: the ticket may follow
+}
+
+// The last arriver of utterance b: pull the `arrivals` partials and the H scores with agent-scope loads only, merge, write
+// out / head_w.  All threads of the workgroup call this (uniform control flow).  lds: fwd_lds_head_floats() floats.
 template <bool VEC4>
 __device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* lds) {
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-    const int H = p.H, dh = p.dh, hpad = round_up_i(H, 4);
-    float* ws = lds;            // [H] softmax-over-heads weights
-    float* part = lds + hpad;   // [ceil(H/8)][dh]
+    const int H = p.H, dh = p.dh, A = p.arrivals, hpad = round_up_i(H, 4), pitch = part_pitch(dh);
+    float* fw = lds;                 // [A <= H] e^(M_a - M)
+    float* stat = lds + hpad;        // {1/S}
+    const float* pg = p.exch_p + (size_t)b * A * pitch;
     const float* ug = p.exch_u + (size_t)b * hpad;
-    const float* cg = p.ctx + (size_t)b * H * dh;
-    constexpr int CH = 8;  // context vectors per work item (independent loads in flight per lane)
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const int nvec = dh >> 2, nch = (H + CH - 1) / CH, items = nvec * nch;
-    f4 cv[CH];
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cg), 0, H * dh * 4, 0x00020000);
-    auto fetch = [&](int item) {
-        const int chunk = item / nvec, dv = item - chunk * nvec;
+    constexpr int CH = 8;            // partial vectors a thread keeps in flight
+    hs_f4 pv[CH];
+    const int nq = dh >> 2;
+    if constexpr (VEC4) {            // the one round of vector loads goes out before anything waits
+        if (tid < nq) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int hh = chunk * CH + k;
-            if (hh < H)
-                cv[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (hh * dh + dv * 4) * 4, 0, 16));
+            for (int k = 0; k < CH; ++k)
+                if (k < A) pv[k] = load_agent4(pg, (k * pitch + 4 + tid * 4) * 4, A * pitch * 4);
         }
-    };
-    if constexpr (VEC4) {
-        if (tid < items) fetch(tid);     // the one round of agent-scope vector loads, issued before anything waits
     }
-    // softmax over heads in wave 0's registers (lane <-> head), DPP reductions, no dependent LDS round trips
     if (tid < 64) {
-        float mx = -INFINITY;
-        for (int h0 = 0; h0 < H; h0 += 64) {
-            const int hh = h0 + lane;
-            float v = -INFINITY;
-            if (hh < H) {
-                v = load_agent(ug + hh);
-                if (p.keep != nullptr && p.keep[(size_t)b * H + hh] == 0) v = -INFINITY;
-                ws[hh] = v;
+        // every load of this wave goes out before anything waits: lane k the header {M_k, S_k} of partial k, lane h the score u_h
+        // (one round trip; more than 64 partials / heads take further rounds)
+        float mk = -INFINITY, sk = 0.f, uh = -INFINITY;
+        if (lane < A) { mk = load_agent(pg + (size_t)lane * pitch); sk = load_agent(pg + (size_t)lane * pitch + 1); }
+        if (lane < H) uh = load_agent(ug + lane);
+        float mx = group_max<64>(mk);
+        for (int a0 = 64; a0 < A; a0 += 64)
+            mx = fmaxf(mx, group_max<64>((a0 + lane < A) ? load_agent(pg + (size_t)(a0 + lane) * pitch) : -INFINITY));
+        const float Mu = (mx == -INFINITY) ? 0.f : mx;
+        const float f0 = (lane < A) ? fast_exp2((mk - Mu) * kLog2e) : 0.f;
+        if (lane < A) fw[lane] = f0;
+        float den = group_sum<64>(f0 * sk);
+        for (int a0 = 64; a0 < A; a0 += 64) {
+            float f = 0.f, sv = 0.f;
+            if (a0 + lane < A) {
+                f = fast_exp2((load_agent(pg + (size_t)(a0 + lane) * pitch) - Mu) * kLog2e);
+                sv = load_agent(pg + (size_t)(a0 + lane) * pitch + 1);
+                fw[a0 + lane] = f;
             }
-            mx = fmaxf(mx, group_max<64>(v));
+            den += group_sum<64>(f * sv);
         }
-        float den = 0.f;
-        for (int h0 = 0; h0 < H; h0 += 64) {
-            const int hh = h0 + lane;
-            const float e = (hh < H) ? fast_exp2((ws[hh] - mx) * kLog2e) : 0.f;   // all masked: NaN, as the reference
-            den += group_sum<64>(e);
-            if (hh < H) ws[hh] = e;
-        }
-        const float inv = 1.0f / den;
-        for (int h0 = 0; h0 < H; h0 += 64) {
-            const int hh = h0 + lane;
-            if (hh < H) {
-                const float wv = ws[hh] * inv;
-                ws[hh] = wv;
-                if (p.head_w != nullptr) p.head_w[(size_t)b * H + hh] = wv;
-            }
+        const float inv = 1.0f / den;                       // all heads masked: 1/0, and out = 0 * inf = NaN like the reference
+        if (lane == 0) stat[0] = inv;
+        if (p.head_w != nullptr) {
+            if (lane < H) p.head_w[(size_t)b * H + lane] = fast_exp2((uh - Mu) * kLog2e) * inv;
+            for (int h0 = 64; h0 < H; h0 += 64)
+                if (h0 + lane < H)
+                    p.head_w[(size_t)b * H + h0 + lane] = fast_exp2((load_agent(ug + h0 + lane) - Mu) * kLog2e) * inv;
         }
     }
     __syncthreads();
+    const float inv = stat[0];
     if constexpr (VEC4) {
-        for (int item = tid; item < items; item += nthr) {
-            if (item != tid) fetch(item);
-            const int chunk = item / nvec, dv = item - chunk * nvec;
-            float wk[CH];
+        for (int q = tid; q < nq; q += nthr) {
+            hs_f4 o = {0.f, 0.f, 0.f, 0.f};
+            for (int a0 = 0; a0 < A; a0 += CH) {
+                if (a0 > 0 || q != tid) {
 #pragma unroll
-            for (int k = 0; k < CH; ++k) wk[k] = (chunk * CH + k < H) ? ws[chunk * CH + k] : 0.f;
-            f4 o = {0.f, 0.f, 0.f, 0.f};
+                    for (int k = 0; k < CH; ++k)
+                        if (a0 + k < A) pv[k] = load_agent4(pg, ((a0 + k) * pitch + 4 + q * 4) * 4, A * pitch * 4);
+                }
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (chunk * CH + k < H) o += wk[k] * cv[k];
-            if (nch == 1) *reinterpret_cast<f4*>(p.out + (size_t)b * dh + dv * 4) = o;
-            else *reinterpret_cast<f4*>(part + (size_t)chunk * dh + dv * 4) = o;
-        }
-        if (nch > 1) {
-            __syncthreads();
-            for (int dv = tid; dv < nvec; dv += nthr) {
-                f4 o = *reinterpret_cast<const f4*>(part + dv * 4);
-#pragma unroll 4
-                for (int c2 = 1; c2 < nch; ++c2) o += *reinterpret_cast<const f4*>(part + (size_t)c2 * dh + dv * 4);
-                *reinterpret_cast<f4*>(p.out + (size_t)b * dh + dv * 4) = o;
+                for (int k = 0; k < CH; ++k)
+                    if (a0 + k < A) o += fw[a0 + k] * pv[k];
             }
+            *reinterpret_cast<hs_f4*>(p.out + (size_t)b * dh + q * 4) = o * inv;
         }
     } else {
         for (int d = tid; d < dh; d += nthr) {
             float o = 0.f;
-            for (int hh = 0; hh < H; ++hh) o = fmaf(ws[hh], load_agent(cg + (size_t)hh * dh + d), o);
-            p.out[(size_t)b * dh + d] = o;
+            for (int k = 0; k < A; ++k) o = fmaf(fw[k], load_agent(pg + (size_t)k * pitch + 4 + d), o);
+            p.out[(size_t)b * dh + d] = o * inv;
         }
     }
 }
 
-// Publication, step 1 (before the alignment stores): every wave drains its write-through stores of
-// ctx / exch_u, the workgroup joins, ONE lane takes a ticket on the utterance's arrival counter.
-// Returns the ticket (meaningful in thread 0 only); its latency hides behind the alignment stores.
-__device__ __forceinline__ int arrive(const FwdParams& p, int b) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    DASV_STAMP(p, 4);
+// The workgroup's tail: fold + publish + ticket by wave 0, the election result to everybody through LDS, the head stage by
+// the workgroup that drew the last ticket.  Called by all threads behind the barrier that made cbuf / ubuf visible; `between`
+// runs after the ticket has been requested (work whose latency should hide the ticket's: the alignment stores).
+template <bool VEC4, typename Between>
+__device__ __forceinline__ void publish_and_finish(const FwdParams& p, int b, int a, const float* cbuf, const float* ubuf,
+                                                   float* lds_head, int* lds_flag, Between between) {
     int ticket = 0;
-    if (threadIdx.x == 0)
-        ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ticket;
-}
-
-// Publication, step 2: the workgroup that drew the last ticket runs the head stage.
-template <bool VEC4>
-__device__ __forceinline__ void finish_if_last(const FwdParams& p, int b, int ticket, float* lds_head, int* lds_flag) {
+    if (threadIdx.x < 64) {
+        fold_publish<VEC4>(p, b, a, cbuf, ubuf);
+        DASV_STAMP(p, 4);
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    between();
     if (threadIdx.x == 0) {
         const int last = (ticket == p.arrivals - 1);
         if (last) __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // leave it zeroed
         *lds_flag = last;
     }
-    __syncthreads();   // also: every wave is past its last use of the stream-phase LDS the head stage aliases
+    __syncthreads();   // also: every wave is past its last use of the LDS the head stage aliases
     DASV_STAMP(p, 5);
     if (*lds_flag == 0) return;
     head_stage<VEC4>(p, b, lds_head);
@@ -250,7 +285,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
 
     float* s_lds = smem + (size_t)uu * p.t_pad;
     float* red_ml = smem + (size_t)upw * p.t_pad;             // [upw*wpu][2]
-    float* red_acc = red_ml + (size_t)upw * wpu * 2;          // [upw*P][DH]
+    float* red_acc = red_ml + (size_t)round_up_i(upw * wpu * 2, 4);   // [upw*P][DH], 16-byte aligned
     int* flag = reinterpret_cast<int*>(smem + fwd_lds_floats(upw, p.t_pad, wpu, P, H, DH) - 4);
 
     const char* xrow = static_cast<const char*>(p.x) +
@@ -406,8 +441,10 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { fw[k] = fast_exp2(mwv[k] - Mu); L = fmaf(lwv[k], fw[k], L); }
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
+    float* cbuf = red_acc + (size_t)upw * P * DH;            // [upw][DH] the workgroup's context vectors
+    float* ubuf = cbuf + (size_t)upw * DH;                   // [upw] their (masked) head scores
     if (wu == 0) {
-        float* cg = p.ctx + ((size_t)b * H + h) * DH;
+        float* cg = p.ctx != nullptr ? p.ctx + ((size_t)b * H + h) * DH : nullptr;
         const float* ua = red_acc + (size_t)uu * P * DH;
         float upart = 0.f;
 #pragma unroll
@@ -425,13 +462,14 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
                     }
                 }
                 const float cv = v * invL;
-                store_agent(cg + d, cv);
+                if (cg != nullptr) cg[d] = cv;               // a plain output: nothing in this launch reads it back
+                cbuf[(size_t)uu * DH + d] = cv;
                 upart = fmaf(cv, attv[kd], upart);
             }
         }
         if (p.att != nullptr) {
             upart = group_sum<64>(upart);
-            if (lane == 0) store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, upart);
+            if (lane == 0) ubuf[uu] = (p.keep != nullptr && p.keep[(size_t)b * H + h] == 0) ? -INFINITY : upart;
         }
         if (p.ml != nullptr && lane == 0) {
             p.ml[((size_t)b * H + h) * 2] = M;
@@ -439,15 +477,16 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         }
     }
     DASV_STAMP(p, 3);
-    int ticket = 0;
-    if (p.att != nullptr) ticket = arrive(p, b);
-    if (p.align != nullptr) {
-        const int tu = wu * 64 + lane, nthr_u = wpu * 64;
-        float* ag = p.align + (size_t)b * T * H + h;
-        for (int t = tu; t < T; t += nthr_u) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
-    }
-    if (p.att == nullptr) return;
-    finish_if_last<true>(p, b, ticket, smem, flag);
+    auto write_align = [&]() {
+        if (p.align != nullptr) {
+            const int tu = wu * 64 + lane, nthr_u = wpu * 64;
+            float* ag = p.align + (size_t)b * T * H + h;
+            for (int t = tu; t < T; t += nthr_u) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+        }
+    };
+    if (p.att == nullptr) { write_align(); return; }
+    __syncthreads();                                         // cbuf / ubuf of every unit are in LDS
+    publish_and_finish<true>(p, b, a, cbuf, ubuf, smem, flag, write_align);
     DASV_STAMP(p, 6);
 }
 
@@ -506,13 +545,16 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     float L = 0.f;
     for (int k = 0; k < nw; ++k) L += red[4 + k];
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
-    float* cg = p.ctx + ((size_t)b * H + h) * dh;
+    float* cg = p.ctx != nullptr ? p.ctx + ((size_t)b * H + h) * dh : nullptr;
+    float* cbuf = qs;          // the scaled query is no longer needed: [dh] context vector of this workgroup's one head
+    float* ubuf = red + 12;    // its (masked) head score
     float upart = 0.f;
     for (int d = tid; d < dh; d += nthr) {
         float v = 0.f;
         for (int t = 0; t < len; ++t) v = fmaf(fast_exp2(s_lds[t] - Mu), E::load1(p.x, base + (long long)t * p.st + d), v);
         v *= invL;
-        store_agent(cg + d, v);
+        if (cg != nullptr) cg[d] = v;
+        cbuf[d] = v;
         if (p.att != nullptr) upart = fmaf(v, p.att[d], upart);
     }
     if (p.att != nullptr) {   // head score <c_h, att>: waves -> LDS -> thread 0
@@ -522,22 +564,23 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
         if (tid == 0) {
             float u = 0.f;
             for (int k = 0; k < nw; ++k) u += red[8 + k];
-            store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, u);
+            ubuf[0] = (p.keep != nullptr && p.keep[(size_t)b * H + h] == 0) ? -INFINITY : u;
         }
     }
     if (p.ml != nullptr && tid == 0) {
         p.ml[((size_t)b * H + h) * 2] = M;
         p.ml[((size_t)b * H + h) * 2 + 1] = L;
     }
-    int ticket = 0;
-    if (p.att != nullptr) ticket = arrive(p, b);
-    if (p.align != nullptr) {
-        float* ag = p.align + (size_t)b * T * H + h;
-        for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
-    }
-    if (p.att == nullptr) return;
-    if ((dh & 3) == 0) finish_if_last<true>(p, b, ticket, smem, flag);
-    else finish_if_last<false>(p, b, ticket, smem, flag);
+    auto write_align = [&]() {
+        if (p.align != nullptr) {
+            float* ag = p.align + (size_t)b * T * H + h;
+            for (int t = tid; t < T; t += nthr) ag[(size_t)t * H] = (t < len) ? fast_exp2(s_lds[t] - Mu) * invL : 0.f;
+        }
+    };
+    if (p.att == nullptr) { write_align(); return; }
+    __syncthreads();           // cbuf / ubuf are in LDS
+    if ((dh & 3) == 0) publish_and_finish<true>(p, b, h, cbuf, ubuf, smem, flag, write_align);
+    else publish_and_finish<false>(p, b, h, cbuf, ubuf, smem, flag, write_align);
 }
 
 // ---- read floor (measurement aid, not on the product path) --------------------------------------
@@ -616,9 +659,14 @@ static int largest_divisor_leq(int n, int cap) {
 // zeroed counters: no last arriver was ever elected and those rows of `out` stayed uninitialised.  Batches beyond
 // kCounterSlots utterances run as several launches (fwd_impl).
 constexpr int kCounterSlots = 16384;
-static size_t fixed_workspace_bytes(int B, int H) {
+static size_t scores_workspace_bytes(int B, int H) {
     const int bc = B < kCounterSlots ? B : kCounterSlots;
-    return (size_t)kCounterSlots * sizeof(int) + (size_t)bc * round_up_i(H, 4) * sizeof(float);
+    return (size_t)bc * round_up_i(H, 4) * sizeof(float);
+}
+// counters | [B][round_up(H,4)] head scores | [B][<= H][4 + round_up(dh,4)] per-workgroup partials (sized for one workgroup per head)
+static size_t fixed_workspace_bytes(int B, int H, int dh) {
+    const int bc = B < kCounterSlots ? B : kCounterSlots;
+    return (size_t)kCounterSlots * sizeof(int) + scores_workspace_bytes(B, H) + (size_t)bc * H * part_pitch(dh) * sizeof(float);
 }
 
 template <typename XT>
@@ -627,7 +675,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
                     size_t workspace_bytes, int B, int T, int H, int dh, int64_t sb, int64_t st, hipStream_t stream,
                     int perm_f = 0, int64_t seg = 0) {
     using E = Elem<XT>;
-    if (x == nullptr || query == nullptr || ctx == nullptr) return DASV_E_NULL;
+    if (x == nullptr || query == nullptr || (ctx == nullptr && att == nullptr)) return DASV_E_NULL;
     if (att != nullptr && out == nullptr) return DASV_E_NULL;
     if (B <= 0 || T <= 0 || H <= 0 || dh <= 0) return DASV_E_SHAPE;
     if ((long long)H * dh > (1ll << 24) || (long long)B > (1ll << 24)) return DASV_E_SHAPE;
@@ -642,7 +690,8 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
                                         keep != nullptr ? keep + (size_t)b0 * H : nullptr, lengths != nullptr ? lengths + b0 : nullptr,
                                         out != nullptr ? out + (size_t)b0 * dh : nullptr,
                                         align != nullptr ? align + (size_t)b0 * T * H : nullptr,
-                                        head_w != nullptr ? head_w + (size_t)b0 * H : nullptr, ctx + (size_t)b0 * H * dh,
+                                        head_w != nullptr ? head_w + (size_t)b0 * H : nullptr,
+                                        ctx != nullptr ? ctx + (size_t)b0 * H * dh : nullptr,
                                         ml != nullptr ? ml + (size_t)b0 * H * 2 : nullptr, workspace, workspace_bytes, nb, T, H, dh,
                                         sb, st, stream, perm_f, seg);
             if (rc != 0) return rc;
@@ -655,6 +704,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     p.out = out; p.align = align; p.head_w = head_w; p.ctx = ctx; p.ml = ml;
     p.counters = static_cast<int*>(workspace);
     p.exch_u = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)kCounterSlots * sizeof(int));
+    p.exch_p = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)kCounterSlots * sizeof(int) + scores_workspace_bytes(B, H));
     p.sb = sb; p.st = st; p.seg = seg; p.B = B; p.T = T; p.H = H; p.dh = dh;
     p.t_pad = round_up_i(T, 4);
     p.s_glob = nullptr;
@@ -731,7 +781,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     const bool in_lds = generic_scores_fit_lds(T, H, dh);
     if (!in_lds) {
         if (workspace == nullptr || workspace_bytes < dasv_dmha_workspace_bytes(B, T, H, dh)) return DASV_E_WORKSPACE;
-        p.s_glob = reinterpret_cast<float*>(static_cast<char*>(workspace) + fixed_workspace_bytes(B, H));
+        p.s_glob = reinterpret_cast<float*>(static_cast<char*>(workspace) + fixed_workspace_bytes(B, H, dh));
     }
     const size_t lds = fwd_lds_generic_floats(in_lds ? p.t_pad : 0, H, dh) * sizeof(float);
     if (lds > kGenericLdsCap) return DASV_E_SHAPE;
@@ -768,8 +818,9 @@ const char* dasv_error_string(int code) {
 size_t dasv_dmha_workspace_bytes(int B, int T, int H, int dh) {
     if (B <= 0 || H <= 0) return 0;
     // [kCounterSlots] arrival counters (must be zero between launches; fixed size, see fixed_workspace_bytes) | head scores
-    // | only for utterances too long for the LDS score row: [B*H][round_up(T,4)] raw scores
-    size_t n = dasv::fixed_workspace_bytes(B, H);
+    // | per-workgroup partials | only for utterances too long for the LDS score row: [B*H][round_up(T,4)] raw scores
+    if (dh <= 0) return 0;
+    size_t n = dasv::fixed_workspace_bytes(B, H, dh);
     const int bc = B < dasv::kCounterSlots ? B : dasv::kCounterSlots;
     if (T > 0 && dh > 0 && !dasv::generic_scores_fit_lds(T, H, dh)) n += (size_t)bc * H * dasv::round_up_i(T, 4) * sizeof(float);
     return n;

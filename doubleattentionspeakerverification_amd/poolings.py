@@ -165,7 +165,7 @@ def nhwc_frames_supported(h4, heads):
     return bool(_lib.load().dasv_dmha_nhwc_supported(F, C, heads))
 
 
-def _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align):
+def _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align, want_ctx=True):
     lib = _lib.load()
     B, C, T, F = h4.shape
     dh, H = query.shape
@@ -185,15 +185,18 @@ def _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align):
         lens = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
         if tuple(lens.shape) != (B,):
             raise RuntimeError("lengths must be [B]")
-    ctxv = torch.empty(B, H, dh, **f32)
-    ml = torch.empty(B, H, 2, **f32)
+    # the per-head context vectors and softmax statistics are what the backward pass needs; inference with the head stage in
+    # the launch does not write them at all (1.3 MB per [64,19,5120] map)
+    want_ctx = want_ctx or a is None
+    ctxv = torch.empty(B, H, dh, **f32) if want_ctx else None
+    ml = torch.empty(B, H, 2, **f32) if want_ctx else None
     align = torch.empty(B, T, H, **f32) if want_align else None
     out = torch.empty(B, dh, **f32) if a is not None else None
     head_w = torch.empty(B, H, **f32) if a is not None else None
     ws = _fwd_workspace(dev, lib.dasv_dmha_workspace_bytes(B, T, H, dh))
     with torch.cuda.device(dev):
         rc = lib.dasv_dmha_fwd_nhwc_f32(h4.data_ptr(), q.data_ptr(), _ptr(a), _ptr(keep), _ptr(lens), _ptr(out), _ptr(align),
-                                        _ptr(head_w), ctxv.data_ptr(), ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, F, C, H,
+                                        _ptr(head_w), _ptr(ctxv), _ptr(ml), ws.data_ptr(), ws.numel(), B, T, F, C, H,
                                         _stream_ptr(dev))
         if rc != 0:
             lib.dasv_dmha_workspace_init(ws.data_ptr(), ws.numel(), _stream_ptr(dev))
@@ -207,11 +210,14 @@ class _PoolNHWCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h4, query, att, head_keep, lengths, want_align):
-        q, a, lens, out, align, head_w, ctxv, ml = _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align)
-        ctx.save_for_backward(h4, q, a, lens, head_w, ctxv, ml, out)
+        need_bwd = any(ctx.needs_input_grad[:3])
+        q, a, lens, out, align, head_w, ctxv, ml = _launch_fwd_nhwc(h4, query, att, head_keep, lengths, want_align, want_ctx=need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(h4, q, a, lens, head_w, ctxv, ml, out)
         ctx.q_dtype = query.dtype
         ctx.a_meta = None if att is None else (att.dtype, att.shape)
-        B, H, dh = ctxv.shape
+        dh, H = q.shape
+        B = h4.shape[0]
         if align is None:
             align = torch.empty(0, device=h4.device)
         primary = out if a is not None else ctxv.view(B, H * dh)

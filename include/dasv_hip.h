@@ -62,8 +62,9 @@ const char* dasv_error_string(int code);
  *   out      [B,dh] f32    DoubleMHA output (NULL allowed iff att is NULL)
  *   align    [B,T,H] f32   softmax-over-time alignments (poolings.py:77); NULL => skipped
  *   head_w   [B,H]  f32    softmax-over-heads weights (poolings.py:50); NULL => skipped
- *   ctx      [B,H,dh] f32  per-head context vectors (poolings.py:79); REQUIRED
- *                          (it is also the in-launch exchange buffer between heads)
+ *   ctx      [B,H,dh] f32  per-head context vectors (poolings.py:79): the output when att is
+ *                          NULL, what the backward launch needs otherwise; NULL => skipped
+ *                          (allowed iff att is given: inference)
  *   ml       [B,H,2] f32   softmax statistics saved for backward: (max, sum) of the
  *                          log2-domain scores; NULL => skipped
  *   workspace              dasv_dmha_workspace_bytes() bytes, zeroed ONCE by

@@ -431,7 +431,8 @@ def test_one_cached_workspace_serves_any_sequence_of_batch_sizes():
         np.testing.assert_allclose(hw.cpu().numpy().reshape(B, H), ref["head_w"].reshape(B, H), rtol=1e-4, atol=1e-6)
     # and the C ABI's own statement of it: the counter region does not depend on B
     lib = _lib()
-    assert lib.dasv_dmha_workspace_bytes(1, 10, H, dh) - 1 * H * 4 == lib.dasv_dmha_workspace_bytes(130, 10, H, dh) - 130 * H * 4
+    per_utt = H * 4 + H * (4 + dh) * 4          # head scores + one partial {M, S, 0, 0 | V[dh]} per head at most
+    assert lib.dasv_dmha_workspace_bytes(1, 10, H, dh) - per_utt == lib.dasv_dmha_workspace_bytes(130, 10, H, dh) - 130 * per_utt == 16384 * 4
 
 
 def test_nhwc_map_of_a_very_long_utterance_falls_back_to_the_frames_path():

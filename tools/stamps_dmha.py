@@ -54,7 +54,7 @@ def main():
     out, hw = torch.empty(B, dh, device=dev), torch.empty(B, H, device=dev)
     align = torch.empty(B, T, H, device=dev)
     ctx, ml = torch.empty(B, H, dh, device=dev), torch.empty(B, H, 2, device=dev)
-    ws = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(1 << 24, dtype=torch.uint8, device=dev)
     nwg_max = 8 * ((B + 7) // 8) * H
     stamps = torch.zeros(2 * nwg_max, 8, dtype=torch.int64, device=dev)  # [grid][8] phase stamps, then [grid][8] per-wave loop-done
     tn = [int(v) for v in args.tuning.split(",")]
@@ -74,7 +74,7 @@ def main():
     for i in range(20):
         launch(i, None)
     torch.cuda.synchronize()
-    names = ["start", "pass0 done", "loop done", "unit done", "drained+barrier", "ticket known", "head stage done"]
+    names = ["start", "pass0 done", "loop done", "unit done", "published", "ticket known", "head stage done"]
     agg, ivals, skew = [], [], []
     for rep in range(7):
         stamps.zero_()
