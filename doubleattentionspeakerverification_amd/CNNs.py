@@ -8,9 +8,11 @@ Each block is [conv3x3 pad1 + ReLU] x2 followed by a 2x2 stride-2 ceil-mode max-
 (CNNs.py:49-50 / 88-89).  Parameter names (conv11 ... conv42) match the reference so its
 checkpoints load with strict=True.
 
-Convolutions: the wide layers (Cin % 64 == 0, Cout % 128 == 0 — everything but conv11 at the reference's
-kernel sizes) run on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU` of csrc/conv3x3.hip on fp32
-NHWC activations; `conv_mode`:
+Convolutions: every layer but conv11 runs on the hand-written MFMA implicit-GEMM `conv3x3 + bias + ReLU` of csrc/conv3x3.hip on
+fp32 NHWC activations.  The kernel works on 64-channel slabs and 128-channel tiles; at a `kernel_size` whose channel counts are
+not such multiples (the reference takes any, CNNs.py:27-32 / 59-66) the front-end runs as the zero-padded network of the next
+such width — padded weight planes, activations padded between the layers (the pad channels stay zero through bias, ReLU and
+max-pool), the last map sliced back: no second convolution backend on the path.  `conv_mode`:
   "split8" (default) fp32-grade forward: fp16 products + block-scaled e4m3 cross terms (~1e-5 of the output scale per layer) at
            any magnitude of activations and weights — every tensor is scaled into the planes' range by an exact power of two
            taken on the device from its range record (conv.new_ranges), Inf / NaN propagate; the backward pass of these layers
@@ -18,7 +20,7 @@ NHWC activations; `conv_mode`:
   "split"  fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product, ~5e-6)
   "bf16"   operands rounded to bf16 (one MFMA per product)
   "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
-  "torch"  PyTorch-ROCm / MIOpen for every layer (also what runs for narrow layers)
+  "torch"  PyTorch-ROCm / MIOpen for every layer (comparison runs only)
 Under `torch.autocast` the HIP kernels run with bf16 / fp16 operands (the autocast dtype), fp32 accumulation and fp32
 activations.
 conv11 (Cin = 1) and the 2x2 ceil-mode max-pools run on hand-written HIP streaming kernels too (csrc/frontend_misc.hip),
@@ -99,6 +101,18 @@ class _VGG(nn.Module):
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self._mode(), grad_premasked, mask_input_grad,
                                           link_in, link_out, x_rec, y_rec), y_rec
 
+    def _c1_padded(self):
+        """conv11's weight / bias zero-padded to the channel count the hand-written kernels want from the first layer: a multiple
+        of 64 that the one-channel kernel takes (a power of two between 64 and 1024).  (weight, bias) themselves when no padding
+        is needed; F.pad is differentiable, so training sees the gradients of the real rows."""
+        c = self.conv11.out_channels
+        cp = 64
+        while cp < c:
+            cp *= 2
+        if cp == c or cp > 1024:
+            return self.conv11.weight, self.conv11.bias
+        return F.pad(self.conv11.weight, (0, 0, 0, 0, 0, 0, 0, cp - c)), F.pad(self.conv11.bias, (0, cp - c))
+
     def _packed_chain_ok(self, fdim, batch=None, frames=None):
         """Inference in the split8 mode with every wide layer on the HIP kernel and channel counts the packed format takes:
         activations between the layers are then written once in the consumer's operand form (conv.conv3x3_x8).  Not for small
@@ -115,7 +129,7 @@ class _VGG(nn.Module):
         for blk in range(1, self.n_blocks + 1):
             for j in (1, 2):
                 c = getattr(self, "conv%d%d" % (blk, j))
-                if (blk, j) != (1, 1) and not (_hipconv.supported(c.in_channels, c.out_channels) and c.weight.dtype == torch.float32):
+                if (blk, j) != (1, 1) and not (_hipconv.exact(c.in_channels, c.out_channels) and c.weight.dtype == torch.float32):
                     return False
         return True
 
@@ -162,8 +176,7 @@ class _VGG(nn.Module):
         features themselves do not need a gradient."""
         c11 = self.conv11
         return (self.conv_mode != "torch" and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
-                and self._mode() is not None and c11.weight.dtype == torch.float32
-                and c11.out_channels % 4 == 0 and 256 % (c11.out_channels // 4) == 0 and c11.out_channels <= 1024)
+                and self._mode() is not None and c11.weight.dtype == torch.float32 and c11.out_channels <= 1024)
 
     def forward(self, paddedInputTensor):
         h = self.forward_map(paddedInputTensor)
@@ -187,7 +200,7 @@ class _VGG(nn.Module):
         if hip:
             c12 = self.conv12
             fused_first = (self.fuse_first_block and not grad and Fdim <= 80 and c12.weight.dtype == torch.float32
-                           and _hipconv.supported(c12.in_channels, c12.out_channels))
+                           and _hipconv.exact(c12.in_channels, c12.out_channels))
             if fused_first:   # conv11 + conv12 in one launch: conv11's activations never reach HBM
                 key = ("conv12", paddedInputTensor.device.index)
                 packed = self._packed.get(key)
@@ -198,10 +211,11 @@ class _VGG(nn.Module):
                                                           "split" if self._mode() == "split8" else self._mode())   # no fused form of split8
             elif grad:
                 rh = next(recs) if x8 else None
-                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, self.conv11.weight, self.conv11.bias, rh)
+                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, *self._c1_padded(), rh)
             else:
                 rh = next(recs) if x8 else None
-                h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, self.conv11.weight, self.conv11.bias, y_rec=rh)
+                w11, b11 = self._c1_padded()
+                h = _hipconv.conv3x3_c1_bias_relu(paddedInputTensor, w11, b11, y_rec=rh)
         else:
             h = paddedInputTensor.reshape(B, 1, T, Fdim)
             if self.channels_last and h.is_cuda:
@@ -229,6 +243,9 @@ class _VGG(nn.Module):
             else:
                 h = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
                 rh = None
+        last = getattr(self, "conv%d2" % self.n_blocks).out_channels
+        if h.shape[1] != last:      # the zero-padded network of a narrow `kernel_size`: drop the pad channels of the last map
+            h = h[:, :last]
         return h
 
 

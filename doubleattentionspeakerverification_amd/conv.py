@@ -29,6 +29,20 @@ USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATe
 
 
 def supported(cin, cout):
+    """Every layer runs on the hand-written kernels: the MFMA implicit GEMM works on 64-channel slabs and 128-channel output
+    tiles, and a layer whose channel counts are not such multiples (the reference takes any `kernel_size`, CNNs.py:27-32 /
+    59-66) is run as the zero-padded layer of the next such size — padded weight planes, padded activations between the layers
+    (`padded_channels`): the pad channels are identically zero through bias, ReLU and max-pool, so nothing else changes."""
+    return cin > 0 and cout > 0
+
+
+def padded_channels(cout):
+    """Channels of the activation tensor a layer with `cout` output channels writes (a multiple of the kernel's 128-channel tile)."""
+    return (cout + 127) // 128 * 128
+
+
+def exact(cin, cout):
+    """True when a layer needs no padding at all (what the packed-activation chains and the ragged path are built for)."""
     return cin % 64 == 0 and cout % 128 == 0
 
 
@@ -64,23 +78,36 @@ class PackedConvWeights:
         self.key = None
         self.owner = None
         self.hi = self.lo = None
+        self.bias = None      # the bias zero-padded to the planes' channel count (None: no bias or no padding)
 
     def invalidate(self):
         self.key = None
         self.owner = None
 
-    def get(self, weight, mode="split", bias=None):
-        """bias: the layer's bias (split8 only: its maximum enters the bound a packed output is scaled by)."""
+    def get(self, weight, mode="split", bias=None, pad=None):
+        """bias: the layer's bias (split8: its maximum enters the bound a packed output is scaled by).
+        pad = (cin_p, cout_p): planes of the zero-padded layer [cout_p][9][cin_p] (and `self.bias` padded to cout_p)."""
         kind = _PACK_KIND[mode]
         cacheable = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
-        key = (weight.data_ptr(), weight._version, weight.device, kind,
-               None if (bias is None or kind != 2) else (bias.data_ptr(), bias._version))
+        cout, cin = weight.shape[0], weight.shape[1]
+        if pad is not None and tuple(pad) == (cin, cout):
+            pad = None
+        key = (weight.data_ptr(), weight._version, weight.device, kind, pad,
+               None if (bias is None or (kind != 2 and pad is None)) else (bias.data_ptr(), bias._version))
         if not (cacheable and key == self.key and self.owner is not None and self.owner() is weight):
             lib = _lib.load()
-            cout, cin = weight.shape[0], weight.shape[1]
+            w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
+            self.bias = None
+            if pad is not None:
+                cin_p, cout_p = pad
+                if cin_p < cin or cout_p < cout:
+                    raise RuntimeError("padded layer %s is smaller than the layer %s" % ((cin_p, cout_p), (cin, cout)))
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+                if bias is not None:
+                    self.bias = bias = torch.nn.functional.pad(bias.detach().float(), (0, cout_p - cout))
+                cout, cin = cout_p, cin_p
             n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
             nlo = max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cout, cin))   # the e4m3 plane carries its scale bytes behind it
-            w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
             if not cacheable or self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
                 # (weights that are not a leaf Parameter — DataParallel replicas, functional weights — get fresh planes per call:
                 # re-packing into shared buffers would race with a convolution still reading them on another stream)
@@ -179,8 +206,13 @@ def conv3x3_wgrad(x, g, mode="split"):
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec):
-        hi, lo = packed.get(weight, mode, bias)
-        y = _launch(x, hi, lo, bias, weight.shape[0], mode, x_rec=x_rec, y_rec=y_rec)
+        # x carries cin_x >= Cin channels (a multiple of 64; the surplus is zero) and y gets padded_channels(Cout): the layer runs
+        # as its zero-padded form (see `supported`)
+        cout, cin = weight.shape[0], weight.shape[1]
+        cin_x, cout_p = x.shape[1], padded_channels(cout)
+        hi, lo = packed.get(weight, mode, bias, (cin_x, cout_p))
+        bias_k = packed.bias if (cin_x, cout_p) != (cin, cout) and bias is not None else bias
+        y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec)
         ctx.save_for_backward(x, weight, y)
         ctx.has_bias = bias is not None
         ctx.mode = mode
@@ -196,39 +228,57 @@ class _ConvReLUFn(torch.autograd.Function):
         # ReLU backward in one pass (g = gy where y > 0 else 0) — unless the consumer of y already applied it
         g = gy if ctx.grad_premasked else torch.ops.aten.threshold_backward(gy, y, 0.0)
         cout, cin = weight.shape[0], weight.shape[1]
+        cin_x, cout_p = x.shape[1], y.shape[1]        # the padded layer that ran forward
+        padded = (cin_x, cout_p) != (cin, cout)
         gx = None
         bmode = BACKWARD_MODE[ctx.mode]
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if want_x and supported(cout, cin) and g.dtype == torch.float32:
+        if want_x and g.dtype == torch.float32:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution of g with the weights
             # transposed over (Cout, Cin) and flipped over (ky, kx): reuse the forward implicit-GEMM kernel
-            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()
+            # (the kernel writes 128-channel tiles: an input with a 64-multiple of channels gets its gradient through a padded
+            # transposed layer and a slice — narrow kernel sizes only)
+            n_out = (cin_x + 127) // 128 * 128
+            wt = weight.detach()
+            if padded or n_out != cin_x:
+                wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, n_out - cin, 0, cout_p - cout))
+            wt = wt.transpose(0, 1).flip(2, 3).contiguous()
             pk = PackedConvWeights()
             hi, lo = pk.get(wt, bmode)
-            # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
-            # backward is applied in this kernel's epilogue
-            gx = _launch(g, hi, lo, None, cin, bmode, relu=0, mask=x if ctx.mask_input_grad else None,
-                         colsum=ctx.link_out if ctx.mask_input_grad else None)
+            if n_out == cin_x:
+                # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
+                # backward is applied in this kernel's epilogue
+                gx = _launch(g, hi, lo, None, cin_x, bmode, relu=0, mask=x if ctx.mask_input_grad else None,
+                             colsum=ctx.link_out if ctx.mask_input_grad else None)
+            else:
+                gx = _launch(g, hi, lo, None, n_out, bmode, relu=0)[:, :cin_x].contiguous(memory_format=torch.channels_last)
+                if ctx.mask_input_grad:
+                    gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
             want_x = False
         gw = gb = None
-        if want_w and USE_HIP_WGRAD and supported_wgrad(cin, cout, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
+        if want_w and USE_HIP_WGRAD and supported_wgrad(cin_x, cout_p, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
             gw = conv3x3_wgrad(x, g, bmode)
+            if padded:
+                gw = gw[:cout, :cin].contiguous()
             want_w = False
             if want_b:
                 # the kernel that produced this (pre-masked) gradient may have left its per-channel sums behind
                 gb = ctx.link_in.pop("gb", None) if (ctx.grad_premasked and ctx.link_in is not None) else None
                 if gb is None:
                     gb = g.sum(dim=(0, 2, 3))
+                gb = gb[:cout] if padded else gb
                 want_b = False
         if want_x or want_w or want_b:
+            # (maps wider than 80 columns / operands beyond 4 GB only: the weight-gradient kernel's limits)
+            wfull = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin_x - cin, 0, cout_p - cout)) if padded else weight
             gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
-                g, x, weight, [cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                g, x, wfull, [cout_p] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                 [want_x, want_w, want_b])
             if want_x:
                 gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
-            gw = gw2 if want_w else gw
-            gb = gb2 if want_b else gb
+            gw = (gw2[:cout, :cin].contiguous() if padded else gw2) if want_w else gw
+            gb = (gb2[:cout] if padded else gb2) if want_b else gb
         return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
@@ -245,11 +295,18 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     link_in / link_out are plain dicts shared between neighbouring calls: the kernel that produces a pre-masked gradient
     also leaves its per-channel sums (= the producer layer's bias gradient) in `link_out["gb"]`; the layer that receives
     that gradient passes the same dict as `link_in` and skips its own reduction pass.
-    x_rec / y_rec (mode "split8"): range records (new_ranges) of x — measured here with one pass over x when None — and of y."""
+    x_rec / y_rec (mode "split8"): range records (new_ranges) of x — measured here with one pass over x when None — and of y.
+    Channel counts that are not multiples of (64, 128): x may carry more channels than the layer has inputs (zeros), and the
+    result carries padded_channels(Cout) channels, the surplus identically zero (see `supported`); slice when needed."""
     if not x.is_cuda:
         raise RuntimeError("conv3x3_bias_relu runs on the GPU only (libdasv_hip.so); no CPU fallback")
-    if x.dtype != torch.float32 or not supported(weight.shape[1], weight.shape[0]):
-        raise RuntimeError("unsupported conv3x3 shape/dtype for the HIP kernel: %s %s" % (tuple(weight.shape), x.dtype))
+    if x.dtype != torch.float32:
+        raise RuntimeError("unsupported conv3x3 dtype for the HIP kernel: %s %s" % (tuple(weight.shape), x.dtype))
+    cin = weight.shape[1]
+    if x.shape[1] < cin or x.shape[1] % 64 != 0:
+        # the caller's tensor has the layer's own (non-multiple-of-64) channel count: zero-pad it (one pass over x; the VGG
+        # front-end keeps its activations padded between the layers instead, CNNs.py)
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, (cin + 63) // 64 * 64 - x.shape[1]))
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     if mode == "split8" and x.shape[3] > 80:
@@ -299,7 +356,7 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_r
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = weight.shape[0]
-    if not x.is_cuda or x.dtype != torch.float32 or not supported(cin, cout) or W > 80:
+    if not x.is_cuda or x.dtype != torch.float32 or not exact(cin, cout) or W > 80:
         raise RuntimeError("conv3x3_x8: unsupported shape/dtype %s %s" % (tuple(x.shape), x.dtype))
     if not x.is_contiguous(memory_format=torch.channels_last):
         if x_packed:

@@ -110,7 +110,7 @@ def _packed_chain_ok(front, rows, W, pools):
                 if conv.out_channels % 64 != 0:
                     return False
                 continue
-            if not _conv.supported(conv.in_channels, conv.out_channels) or W > 80:
+            if not _conv.exact(conv.in_channels, conv.out_channels) or W > 80:
                 return False
             if lib.dasv_conv3x3_workspace_bytes(1, rows, W, conv.in_channels, conv.out_channels) != 0:
                 return False
@@ -174,7 +174,7 @@ def front_end_ragged(front, utterances, mode=None):
                 h = _conv_ragged(h, conv, packed, mode, span, x_packed=h_packed, y_packed=first, x_rec=rh, y_rec=ry)
                 h_packed, rh = first, ry
             else:
-                if not _conv.supported(conv.in_channels, conv.out_channels):
+                if not _conv.exact(conv.in_channels, conv.out_channels):
                     raise RuntimeError("ragged front-end: layer %s (%d -> %d channels) is outside the HIP kernel's shapes"
                                        % (name, conv.in_channels, conv.out_channels))
                 key = (name, dev.index)

@@ -222,3 +222,65 @@ def test_timed_paths_against_the_oracle_front_ends():
             y = net4(xl.to(DEV)).cpu()
             ref = oracle.vgg_forward(xl[:1], sd4, 4)
         assert y.shape == (B, 50, 5120) and _rel(y[:1], ref) < 5e-5, B
+
+
+@pytest.mark.parametrize("ks,heads", [(512, 32), (256, 16), (48, 4)])
+def test_narrow_kernel_sizes_run_on_the_hip_kernels_vs_oracle(ks, heads, monkeypatch):
+    """VERDICT r2 task 5: the reference takes any kernel_size (CNNs.py:27-32 / 59-66); widths whose channel counts are not
+    multiples of the MFMA kernel's slabs used to fall back to PyTorch-ROCm/MIOpen — a second backend on the hot path.  They now
+    run as the zero-padded network on the hand-written kernels: a spy on F.conv2d must see no call, forward or training step,
+    and the embeddings equal the oracle's (model.py:52-59)."""
+    import torch.nn.functional as F
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    torch.manual_seed(77)
+    net = SpeakerClassifier(_default_params(ks=ks, heads=heads, spk=40), torch.device(DEV)).to(DEV).eval()
+    calls = []
+    real = F.conv2d
+    monkeypatch.setattr(F, "conv2d", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = torch.from_numpy(rnd(55, 4, 150, 80))
+    with torch.no_grad():
+        emb = net.getEmbedding(x.to(DEV)).cpu()
+        emb1 = net.getEmbedding(x[:1].to(DEV)).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    net.train()
+    lab = torch.tensor([1, 5, 5, 12], device=DEV)
+    _, logits = net(x.to(DEV), label=lab, step=0)
+    torch.nn.functional.cross_entropy(logits, lab).backward()
+    assert not calls, "F.conv2d was called %d times: a layer left the hand-written kernels" % len(calls)
+    for name in ("conv11", "conv12", "conv21", "conv42"):
+        g = getattr(net.front_end, name).weight.grad
+        assert g is not None and g.shape == getattr(net.front_end, name).weight.shape and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    monkeypatch.undo()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = oracle.embedding_forward(x, sd, 4, heads)
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("kernel_size %d: embedding rel err %.2e (B=1 %.2e), min cosine %.8f" % (ks, _rel(emb, ref), _rel(emb1, ref[:1]), cos))
+    assert _rel(emb, ref) < 1e-4 and _rel(emb1, ref[:1]) < 1e-4 and 1 - cos < 1e-5
+
+
+def test_narrow_kernel_size_training_gradients_match_pytorch():
+    """The zero-padded network's gradients (padded data-gradient / weight-gradient launches, sliced back) against PyTorch-ROCm's
+    for kernel_size 256 (channels 32 ... 256)."""
+    import copy
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    torch.manual_seed(5)
+    net = VGG4L(256).to(DEV).train()
+    ref = copy.deepcopy(net)
+    ref.conv_mode = "torch"
+    x = torch.from_numpy(rnd(61, 2, 45, 80)).to(DEV)
+    gout = None
+    grads = {}
+    for tag, m in (("hip", net), ("torch", ref)):
+        y = m(x)
+        if gout is None:
+            gout = torch.from_numpy(rnd(62, *y.shape)).to(DEV)
+        (y * gout).sum().backward()
+        grads[tag] = {k: v.grad.clone() for k, v in m.named_parameters()}
+    for k in grads["torch"]:
+        a, b = grads["hip"][k], grads["torch"][k]
+        assert a.shape == b.shape
+        cosv = float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+        # direction and size, not each element: on these small maps one ReLU sign / pool arg-max decided the other way by the
+        # ~1e-5 forward difference moves a channel's gradient by percents (tools/_diag/narrow_grad.py: single layers agree to 6e-6)
+        assert cosv > 0.9995 and float((a - b).abs().max()) <= 5e-2 * float(b.abs().max()), (k, cosv)
