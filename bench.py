@@ -37,6 +37,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 MFMA_BF16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the conv's MFMAs are bf16, fp32 accumulate)
 
 
+def _lib_mod():
+    from doubleattentionspeakerverification_amd import _lib
+    return _lib
+
+
 def default_params():
     return argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32,
                               mask_prob=0.3, embedding_size=400, num_spkrs=5994, scalingFactor=30.0,
@@ -166,10 +171,11 @@ def pooling_config2(poolings, lib, dev, launches=200, reps=5):
         return sorted(out)[len(out) // 2]
 
     pool_us = timed(lambda i: plan(xs[i % 8]))
-    variant = lib.dasv_debug_last_variant().decode()
+    variant = lib.dasv_dmha_last_variant().decode()
+    probe = _lib_mod().debug_probe()      # the read-floor kernel lives in the developer build of the library only
 
     def floor(i):
-        rc = lib.dasv_debug_read_floor(xs[i % 8].data_ptr(), nbytes, scratch.data_ptr(), stream)
+        rc = probe.dasv_debug_read_floor(xs[i % 8].data_ptr(), nbytes, scratch.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError("dasv_debug_read_floor rc=%d" % rc)
     floor_us = timed(floor)
@@ -184,7 +190,7 @@ def pooling_config2(poolings, lib, dev, launches=200, reps=5):
         nbb = Bb * T * D * 4
 
         def big_floor(i):
-            lib.dasv_debug_read_floor(xb[i % 2].data_ptr(), nbb, scratch.data_ptr(), stream)
+            probe.dasv_debug_read_floor(xb[i % 2].data_ptr(), nbb, scratch.data_ptr(), stream)
         launches = 50
         pb = timed(lambda i: planb(xb[i % 2]))
         fb = timed(big_floor)
@@ -270,6 +276,56 @@ def cpu_baseline_pool(B, T, D, H, seconds=10.0):
     return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d utterances of [%d,%d] through oracle.dmha_opseq (torch CPU fp32, the reference's op "
                        "sequence poolings.py:73-80,45-51), %.1f s" % (n, T, D, dt))
+
+
+def timed_regions(run_steps, warmup, steps, regions, dist, dev):
+    """The driver's timing contract, `regions` times: W untimed warm-up steps once, then per region EXACTLY `steps` steps bracketed
+    by barrier + synchronize on both sides, the MAX over ranks of its wall time; returns (elapsed of the MEDIAN region in seconds,
+    that region's HIP-event milliseconds on this rank's stream or None on the CPU, all regions' elapsed).  Device-agnostic so
+    that the multi-rank path is exercised on gloo/CPU by tests/test_dist_cpu.py."""
+    cuda = torch.device(dev).type == "cuda"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+
+    run_steps(0, warmup)
+    regs = []
+    first = warmup
+    for _ in range(max(1, regions)):
+        barrier()
+        ev0 = ev1 = None
+        if cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if cuda:
+            ev0.record()
+        run_steps(first, steps)
+        if cuda:
+            ev1.record()
+        barrier()
+        el = time.perf_counter() - t0
+        first += steps
+        regs.append((el, ev0.elapsed_time(ev1) if cuda else None))
+    els = torch.tensor([r[0] for r in regs], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(els, op=dist.ReduceOp.MAX)
+    els = [float(v) for v in els.tolist()]
+    mid = sorted(range(len(els)), key=lambda i: els[i])[len(els) // 2]
+    return els[mid], regs[mid][1], els
+
+
+def headline(metric, unit, units_per_rank_step, world, steps, warmup, elapsed, els, dist):
+    """The fields of the JSON line that every workload shares: `value` is the WHOLE-JOB rate (all ranks' units over the median
+    region's max-over-ranks time); `dist` says what torch.distributed reports, so that an N-GPU run can be checked to have had N ranks."""
+    return {"metric": metric, "value": round(units_per_rank_step * world * steps / elapsed, 2), "unit": unit,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "regions": {"count": len(els), "steps_each": steps, "elapsed_s": [round(v, 5) for v in els], "quoted": "median"},
+            "dist": {"world_size": (dist.get_world_size() if dist is not None else 1),
+                     "backend": (dist.get_backend() if dist is not None else None)}}
 
 
 def main():
@@ -434,34 +490,17 @@ def main():
         for i in range(count):
             step(first + i)
 
+    # warm-up, then `--regions` timed regions of exactly `--steps` steps (timed_regions); the line quotes the MEDIAN region (one
+    # real region: ms_per_step x steps is its wall time).  Several regions because one region of the embedding workload is
+    # 0.1 s — too short for a sampler outside the process to see the GPU busy, and a single region inherits whatever clock
+    # state the warm-up left.
     run_steps(0, args.warmup)
     timer.active = True
     ctimer.active = True
-    # `--regions` timed regions of exactly `--steps` steps, each bracketed by barrier + synchronize on both sides; per region the
-    # MAX over ranks; the line quotes the MEDIAN region (one real region: ms_per_step x steps is its wall time).  Several regions
-    # because one region of the embedding workload is 0.1 s — too short for a sampler outside the process to see the GPU busy,
-    # and a single region inherits whatever clock state the warm-up left.
-    regions = []
-    first = args.warmup
-    for _ in range(max(1, args.regions)):
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        run_steps(first, args.steps)
-        ev1.record()
-        barrier()
-        el = time.perf_counter() - t0
-        first += args.steps
-        regions.append((el, ev0.elapsed_time(ev1)))
+    elapsed, region_ms, els = timed_regions(lambda first, count: run_steps(args.warmup + first, count), 0, args.steps, args.regions, dist, dev)
     timer.active = False
     ctimer.active = False
-    els = torch.tensor([r[0] for r in regions], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(els, op=dist.ReduceOp.MAX)
-    els = [float(v) for v in els.tolist()]
-    mid = sorted(range(len(els)), key=lambda i: els[i])[len(els) // 2]
-    elapsed, region_ms = els[mid], regions[mid][1]
+    nstep_timed = args.steps * len(els)
 
     if rank == 0:
         Bp, Tp, Dp, Hp = pool_shape
@@ -476,21 +515,22 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(args.workload, args.dtype),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_us": round(pool_us, 3),
-                         "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_debug_last_variant().decode()}
+                         "pool_shape": {"B": Bp, "T": Tp, "D": Dp, "H": Hp}, "variant": lib.dasv_dmha_last_variant().decode()}
             if args.workload == "pool" and compute_dtype == torch.float32:
                 # the read floor on the same rotating buffers: the simplest kernel that reads x once
                 scratch = torch.zeros(4096, device=dev)
+                probe = _lib_mod().debug_probe()
                 sp = torch.cuda.current_stream(dev).cuda_stream
                 nb = Bp * Tp * Dp * 4
                 fl = []
                 for _ in range(5):
                     for i in range(16):
-                        lib.dasv_debug_read_floor(xs[i % nbuf].data_ptr(), nb, scratch.data_ptr(), sp)
+                        probe.dasv_debug_read_floor(xs[i % nbuf].data_ptr(), nb, scratch.data_ptr(), sp)
                     torch.cuda.synchronize()
                     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     f0.record()
                     for i in range(200):
-                        lib.dasv_debug_read_floor(xs[i % nbuf].data_ptr(), nb, scratch.data_ptr(), sp)
+                        probe.dasv_debug_read_floor(xs[i % nbuf].data_ptr(), nb, scratch.data_ptr(), sp)
                     f1.record()
                     torch.cuda.synchronize()
                     fl.append(f0.elapsed_time(f1) * 1e3 / 200)
@@ -529,7 +569,7 @@ def main():
                         "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
                         "traffic": pmc_traffic("embed_conv", args.conv) if args.workload == "embed" else None,
                         "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
-                        "launches_per_step": len(ctimer.rec) // max(1, args.steps * len(els)),
+                        "launches_per_step": len(ctimer.rec) // max(1, nstep_timed),
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
                         "mfma_util_pmc_percent": mfma_util_pmc()}
@@ -567,23 +607,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
             cpu = cpu_baseline_pool(B, T, 512, 8) if args.workload == "pool" else cpu_baseline_embed(default_params(), T)
-        out = {
-            "metric": "utterance-embeddings/sec" if args.workload != "train" else "training utterances/sec",
-            "value": round(B * world * args.steps / elapsed, 2),
-            "unit": "utterance-embeddings/s" if args.workload != "train" else "utterances/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        out = headline("utterance-embeddings/sec" if args.workload != "train" else "training utterances/sec",
+                       "utterance-embeddings/s" if args.workload != "train" else "utterances/s", B, world, args.steps, args.warmup,
+                       elapsed, els, dist)
+        out.update({
             # the arithmetic type of the multiplicands (I/O and accumulation are fp32 everywhere): what the matrix cores multiply
             "dtype": ("f32" if args.workload == "pool" else
                       {"split8": "f32-io/f16+e4m3-split", "split": "f32-io/3xbf16-split", "torch": "f32", "fp16": "f32-io/f16",
                        "bf16": "f32-io/bf16"}[args.conv]) if compute_dtype == torch.float32 else "bf16",
-            "regions": {"count": len(els), "steps_each": args.steps, "elapsed_s": [round(v, 5) for v in els], "quoted": "median"},
-            "dist": {"world_size": (dist.get_world_size() if dist is not None else 1),
-                     "backend": (dist.get_backend() if dist is not None else None)},
             "data": "synthetic (np.random.RandomState(1234), random-init weights under torch.manual_seed(1234))",
             "config": config, "roofline": roofline, "roofline_pooling": pool_roof, "cpu_baseline": cpu,
-        }
+        })
         if companions is not None:
             out["conv_operand_modes"] = companions
         print(json.dumps(out))

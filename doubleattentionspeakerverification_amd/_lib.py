@@ -65,8 +65,12 @@ SIGNATURES = {
     "dasv_dmha_nhwc_supported": (c_int, [c_int, c_int, c_int]),
     "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_bwd_nhwc_f32": (c_int, [c_void_p] * 12 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_dmha_last_variant": (ctypes.c_char_p, []),
+}
+
+# the developer surface: exported by libdasv_hip_dbg.so only (include/dasv_hip.h, #ifdef DASV_DEBUG)
+DEBUG_SIGNATURES = {
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
-    "dasv_debug_last_variant": (ctypes.c_char_p, []),
     "dasv_debug_read_floor": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
 }
 
@@ -81,27 +85,57 @@ def lib_path():
     return _build.lib_path()
 
 
+def _bind(path, signatures):
+    if not os.path.exists(path):
+        raise DasvError(
+            "HIP library %s is not built; run `python -m doubleattentionspeakerverification_amd.build`. "
+            "There is no CPU fallback for this path." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dasv_abi_version() != 2:
+        raise DasvError("%s ABI version %d, expected 2" % (path, lib.dasv_abi_version()))
+    return lib
+
+
 def load():
     """Load (once) and return the bound library.  Raises if it is not built."""
     global _lib
     if _lib is not None:
         return _lib
     with _lock:
-        if _lib is not None:
-            return _lib
-        path = lib_path()
-        if not os.path.exists(path):
-            raise DasvError(
-                "HIP library %s is not built; run `python -m doubleattentionspeakerverification_amd.build`. "
-                "There is no CPU fallback for this path." % path)
-        lib = ctypes.CDLL(path)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
-            fn.restype = res
-            fn.argtypes = args
-        if lib.dasv_abi_version() != 2:
-            raise DasvError("libdasv_hip.so ABI version %d, expected 2" % lib.dasv_abi_version())
-        _lib = lib
+        if _lib is None:
+            _lib = _bind(lib_path(), SIGNATURES)
+    return _lib
+
+
+_probe = None
+
+
+def debug_probe():
+    """libdasv_hip_dbg.so bound for its developer entry points only (bench.py's read-floor probe, kernel sweeps through the C ABI):
+    loaded BESIDE the product library, which keeps serving every module call of the process."""
+    global _probe
+    with _lock:
+        if _probe is None:
+            _probe = _bind(_build.debug_lib_path(), {**SIGNATURES, **DEBUG_SIGNATURES})
+    return _probe
+
+
+def use_debug_library():
+    """Developer runs only (kernel sweeps, the read-floor probe of bench.py, the tests that force a kernel variant): make THIS
+    process launch through libdasv_hip_dbg.so — the same sources built with -DDASV_DEBUG — which also exports the developer
+    surface (dasv_debug_*).  Call before anything else has loaded the product library."""
+    global _lib
+    with _lock:
+        if _lib is not None and not hasattr(_lib, "_dasv_debug"):
+            raise DasvError("the product library is already loaded in this process")
+        if _lib is None:
+            lib = _bind(_build.debug_lib_path(), {**SIGNATURES, **DEBUG_SIGNATURES})
+            lib._dasv_debug = True
+            _lib = lib
     return _lib
 
 

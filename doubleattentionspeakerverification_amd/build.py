@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libdasv_hip.so"
+# the same sources with -DDASV_DEBUG: the developer surface of include/dasv_hip.h (tuning knobs, read-floor probe) lives ONLY in
+# this second library; the product library exports none of it
+DEBUG_LIBNAME = "libdasv_hip_dbg.so"
+DEBUG_SOURCES = ["dmha_fwd.hip"]        # the translation units that contain DASV_DEBUG code
 SOURCES = ["dmha_fwd.hip", "dmha_bwd.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "frontend_misc.hip"]
 HEADERS = ["dasv_common.hpp", os.path.join("..", "..", "include", "dasv_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -42,9 +46,14 @@ def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 
 
+def debug_lib_path():
+    return os.path.join(LIBDIR, DEBUG_LIBNAME)
+
+
 def is_current():
     stamp = os.path.join(LIBDIR, "build.stamp")
-    return os.path.exists(lib_path()) and os.path.exists(stamp) and open(stamp).read().strip() == _stamp()
+    return (os.path.exists(lib_path()) and os.path.exists(debug_lib_path()) and os.path.exists(stamp)
+            and open(stamp).read().strip() == _stamp())
 
 
 def build(force=False, verbose=True):
@@ -53,7 +62,7 @@ def build(force=False, verbose=True):
         return lib_path()
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    objs = []
+    objs, dbg_objs = [], []
     procs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
@@ -65,13 +74,23 @@ def build(force=False, verbose=True):
             print("[dasv build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, cwd=CSRC)))
         objs.append(obj)
+        if src in DEBUG_SOURCES:
+            dobj = os.path.join(LIBDIR, src.replace(".hip", "_dbg.o"))
+            cmd = [hipcc] + FLAGS + ["-DDASV_DEBUG", "-c", path, "-o", dobj]
+            if verbose:
+                print("[dasv build]", " ".join(cmd), flush=True)
+            procs.append((src + " (debug)", subprocess.Popen(cmd, cwd=CSRC)))
+            dbg_objs.append(dobj)
+        else:
+            dbg_objs.append(obj)
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path()] + objs
-    if verbose:
-        print("[dasv build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=CSRC)
+    for out, these in ((lib_path(), objs), (debug_lib_path(), dbg_objs)):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + these
+        if verbose:
+            print("[dasv build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
     with open(os.path.join(LIBDIR, "build.stamp"), "w") as f:
         f.write(_stamp())
     return lib_path()

@@ -395,14 +395,19 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce(const float* __restr
 static void wgrad_plan(int B, int H, int W, int Cin, int Cout, WgradParams& p) {
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ctiles = Cin / 64; p.ntiles = Cout / 64;
-    p.patch = (W % 8 == 0 && getenv("DASV_WGRAD_RASTER") == nullptr) ? 1 : 0;
+#ifndef DASV_WGRAD_RASTER
+#define DASV_WGRAD_RASTER 0   // timing builds only (tools/wgrad_diag.py): 1 forces raster chunks
+#endif
+    p.patch = (W % 8 == 0 && !DASV_WGRAD_RASTER) ? 1 : 0;
     p.chunks_per_image = p.patch ? ((H + 7) / 8) * (W / 8) : (H * W + WKC - 1) / WKC;
     const int total = B * p.chunks_per_image, tiles = p.ctiles * p.ntiles;
     // workgroups per launch the pixel range is split for: one workgroup per CU is resident, so whole multiples of 256 avoid a
     // partial last round; measured sweep over the VGG4L/1024 layers (tools/_diag/wgrad_target_sweep.py, interleaved):
     // 256: 6.43  384: 7.92  512: 6.41 | 512: 6.23  768: 6.36  1024: 6.44  1536: 6.72  2048: 6.94 ms
-    int target = 512;
-    if (const char* e = getenv("DASV_WGRAD_TARGET")) target = atoi(e) > 0 ? atoi(e) : target;   // tuning experiments only
+#ifndef DASV_WGRAD_TARGET
+#define DASV_WGRAD_TARGET 512   // (a compile-time constant: sweeps build their own objects, tools/_diag/wgrad_target_sweep.py)
+#endif
+    const int target = DASV_WGRAD_TARGET;
     int S = (target + tiles - 1) / tiles;
     if (S > total) S = total;
     if (S < 1) S = 1;

@@ -583,7 +583,8 @@ __global__ void __launch_bounds__(256) dmha_fwd_generic(const FwdParams p) {
     else publish_and_finish<false>(p, b, h, cbuf, ubuf, smem, flag, write_align);
 }
 
-// ---- read floor (measurement aid, not on the product path) --------------------------------------
+#ifdef DASV_DEBUG
+// ---- read floor (measurement aid: DASV_DEBUG builds only, libdasv_hip_dbg.so) ---------------------
 // The simplest kernel that reads `nvec` 16-byte vectors once: eight independent loads in flight per thread, grid-stride,
 // one atomic per wave to keep the loads alive.  bench.py times it on the same rotating buffers as the fused kernel: what
 // it needs is the time NO kernel that streams x once can beat on this chip at this size (tools/read_floor.hip swept the
@@ -604,13 +605,18 @@ __global__ void __launch_bounds__(256) read_floor_kernel(const float4* __restric
     acc = group_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.x, acc);
 }
+#endif
 
 // ---- host side --------------------------------------------------------------------------------
 struct Tuning { int nw = 0, wpu = 0, lds_pad = 0, force_generic = 0, rows = 0; };
 #ifdef DASV_STAMPS
 static unsigned long long* g_stamps = nullptr;
 #endif
-static Tuning g_tuning;
+#ifdef DASV_DEBUG
+static Tuning g_tuning;            // sweeps only (dasv_debug_set_tuning)
+#else
+static constexpr Tuning g_tuning{};   // the product library has no knobs: every choice below is the automatic one
+#endif
 static thread_local char g_last_variant[96] = "none";
 
 constexpr int rows_per_pass_for(int ni) { return ni == 1 ? 4 : (ni <= 3 ? 2 : 1); }
@@ -879,6 +885,9 @@ int dasv_dmha_fwd_nhwc_f32(const float* x, const float* query, const float* att,
                                      B, T, H, dh, (int64_t)T * F * C, (int64_t)F * C, (hipStream_t)stream, F, (int64_t)C);
 }
 
+const char* dasv_dmha_last_variant(void) { return dasv::g_last_variant; }
+
+#ifdef DASV_DEBUG
 void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic,
                            int rows_per_pass) {
     dasv::g_tuning.rows = rows_per_pass;
@@ -888,8 +897,6 @@ void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_
     dasv::g_tuning.force_generic = force_generic;
 }
 
-const char* dasv_debug_last_variant(void) { return dasv::g_last_variant; }
-
 int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream) {
     if (x == nullptr || scratch == nullptr) return DASV_E_NULL;
     if (bytes < 16 || (uintptr_t)x % 16 != 0) return DASV_E_SHAPE;
@@ -897,6 +904,8 @@ int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stre
                        static_cast<const float4*>(x), (long long)(bytes / 16), scratch);
     return (int)hipGetLastError();
 }
+
+#endif  // DASV_DEBUG
 
 #ifdef DASV_STAMPS
 void dasv_debug_set_stamps(void* p) { dasv::g_stamps = static_cast<unsigned long long*>(p); }

@@ -18,7 +18,7 @@ from . import _lib
 from . import conv as _conv
 from . import poolings as _pool
 
-__all__ = ["embed_ragged", "embed_ragged_batches", "ragged_tables", "front_end_ragged"]
+__all__ = ["embed_ragged", "embed_ragged_batches", "ragged_tables", "front_end_ragged", "plan_ragged_groups"]
 
 
 def _upload_int64(values, device):
@@ -225,24 +225,44 @@ def embed_ragged(net, utterances, mode=None):
     return net.b2(torch.relu(net.fc2(hidden)))
 
 
-@torch.no_grad()
-def embed_ragged_batches(net, utterances, max_frames=64 * 300, mode=None, rank=0, world=1):
-    """Embeddings of many utterances of arbitrary lengths: greedy groups of up to `max_frames` total frames (the footprint
-    of a [64,300,80] batch by default), each group one ragged pass.  Returns {index: embedding} for the groups this rank
-    owns (round-robin over `world` ranks; all of them when world == 1)."""
-    order = sorted(range(len(utterances)), key=lambda i: -int(utterances[i].shape[0]))   # similar lengths share a group
+def plan_ragged_groups(lengths, max_frames=64 * 300, rank=0, world=1):
+    """Which utterances this rank embeds, and in which groups (pure host arithmetic, the same on every rank: no communication).
+
+    Utterances are dealt to the `world` ranks first — longest first, each to the rank with the fewest frames so far (LPT), so the
+    ranks' total frames differ by at most one utterance — and every rank then packs ITS utterances, longest first, into groups
+    of up to `max_frames` frames (one ragged pass each; similar lengths share a group).  Dealing whole groups instead would
+    leave ranks a full group apart: 26 groups over 8 ranks is 4 against 3 passes.  Returns a list of index lists."""
+    lengths = [int(n) for n in lengths]
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    if world > 1:
+        load = [0] * world
+        mine = []
+        for i in order:
+            r = min(range(world), key=lambda j: (load[j], j))
+            load[r] += lengths[i]
+            if r == rank:
+                mine.append(i)
+    else:
+        mine = order
     groups, cur, frames = [], [], 0
-    for i in order:
-        n = int(utterances[i].shape[0])
-        if cur and frames + n > max_frames:
+    for i in mine:
+        if cur and frames + lengths[i] > max_frames:
             groups.append(cur)
             cur, frames = [], 0
         cur.append(i)
-        frames += n
+        frames += lengths[i]
     if cur:
         groups.append(cur)
+    return groups
+
+
+@torch.no_grad()
+def embed_ragged_batches(net, utterances, max_frames=64 * 300, mode=None, rank=0, world=1):
+    """Embeddings of many utterances of arbitrary lengths: groups of up to `max_frames` total frames (the footprint of a
+    [64,300,80] batch by default), each group one ragged pass.  Returns {index: embedding} for the utterances this rank owns
+    (plan_ragged_groups: utterances dealt to the ranks by frames, then grouped per rank; all of them when world == 1)."""
     out = {}
-    for g in groups[rank::world]:
+    for g in plan_ragged_groups([u.shape[0] for u in utterances], max_frames, rank, world):
         emb = embed_ragged(net, [utterances[i] for i in g], mode)
         for j, i in enumerate(g):
             out[i] = emb[j]

@@ -301,8 +301,15 @@ int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att,
                            float* grad_query, float* grad_att, void* workspace, size_t workspace_bytes, int B, int T, int F,
                            int C, int H, dasv_stream_t stream);
 
+/* name of the kernel variant the last dasv_dmha_fwd call on this thread selected (introspection: smoke tests and bench.py
+ * record it; e.g. "vec<dtype=0,G=16,NI=1,R=4> nw=8 wpu=4 upw=2 lds=11200") */
+const char* dasv_dmha_last_variant(void);
+
+#ifdef DASV_DEBUG
 /* ------------------------------------------------------------------------
- * Developer knobs (benchmark sweeps only; process-global, not thread-safe).
+ * Developer surface — NOT in libdasv_hip.so.  The build also links libdasv_hip_dbg.so from the same sources with
+ * -DDASV_DEBUG; only that library exports what follows (benchmark sweeps and the read-floor probe of bench.py).
+ * Process-global, not thread-safe.
  * waves_per_group: wavefronts per workgroup (0 = auto); waves_per_head: wavefronts
  * cooperating on one (utterance, head) (0 = auto); lds_pad_bytes: extra LDS per
  * workgroup to cap workgroups per CU (0 = none); force_generic: 1 = always take
@@ -311,12 +318,12 @@ int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att,
  * ------------------------------------------------------------------------ */
 void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_bytes, int force_generic,
                            int rows_per_pass);
-/* name of the kernel variant the last dasv_dmha_fwd call on this thread selected */
-const char* dasv_debug_last_variant(void);
 /* Measurement aid: reads `bytes` (16-byte aligned, whole 16-byte vectors) at x once with the simplest possible kernel and
  * adds per-wave sums into scratch[0..2047] (>= 2048 floats, caller-zeroed).  bench.py times it beside the fused pooling
  * kernel: no kernel that streams x once can be faster than this on the same buffers. */
 int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream);
+#endif /* DASV_DEBUG */
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,9 +15,13 @@ def lib_path():
     return build.build(verbose=False)
 
 
-def _declared():
+def _declared(debug=False):
+    """Entry points include/dasv_hip.h declares: the product surface, or (debug=True) the developer surface inside
+    `#ifdef DASV_DEBUG` that only libdasv_hip_dbg.so exports."""
     text = open(os.path.join(ROOT, "include", "dasv_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    m = re.search(r"#ifdef DASV_DEBUG(.*?)#endif", text, flags=re.S)
+    text = m.group(1) if debug else text.replace(m.group(0), "")
     return sorted(set(re.findall(r"\b(dasv_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -32,6 +36,23 @@ def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     for name in _declared():
         assert hasattr(lib, name), "libdasv_hip.so does not export %s" % name
+
+
+def test_developer_surface_is_only_in_the_debug_library(lib_path):
+    """no debug exports and no environment knobs in the product library.  The tuning knobs and the read-floor probe
+    are compiled only under -DDASV_DEBUG into libdasv_hip_dbg.so (same sources); the product library exports none of them and
+    does not import getenv."""
+    import subprocess
+    from doubleattentionspeakerverification_amd import _lib, build
+    prod, dbg = ctypes.CDLL(lib_path), ctypes.CDLL(build.debug_lib_path())
+    assert _declared(debug=True) == sorted(_lib.DEBUG_SIGNATURES) and _declared(debug=True)
+    for name in _declared(debug=True):
+        assert not hasattr(prod, name), name
+        assert hasattr(dbg, name), name
+    for name in _declared():
+        assert hasattr(dbg, name), name
+    syms = subprocess.run(["nm", "-D", lib_path], capture_output=True, text=True).stdout
+    assert "dasv_debug" not in syms and "getenv" not in syms
 
 
 def test_binding_table_covers_the_header(lib_path):

@@ -185,32 +185,53 @@ def test_mha_only_forward_backward_vs_oracle():
     np.testing.assert_allclose(qt.grad.cpu().numpy(), qo.grad.numpy(), rtol=1e-4, atol=2e-5)
 
 
+def _dbg_double_mha(lib, x, q, a):
+    """One forward through the C ABI of the DEVELOPER build (libdasv_hip_dbg.so: same sources + the tuning knobs the product
+    library does not export) — returns (out, align, variant)."""
+    B, T, D = x.shape
+    dh, H = q.shape
+    f32 = dict(dtype=torch.float32, device=x.device)
+    out, align = torch.empty(B, dh, **f32), torch.empty(B, T, H, **f32)
+    hw, ctx, ml = torch.empty(B, H, **f32), torch.empty(B, H, dh, **f32), torch.empty(B, H, 2, **f32)
+    ws = torch.zeros(lib.dasv_dmha_workspace_bytes(B, T, H, dh), dtype=torch.uint8, device=x.device)
+    rc = lib.dasv_dmha_fwd(0, x.data_ptr(), q.data_ptr(), a.data_ptr(), None, None, out.data_ptr(), align.data_ptr(), hw.data_ptr(),
+                           ctx.data_ptr(), ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh, T * D, D,
+                           torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out, align, lib.dasv_dmha_last_variant().decode()
+
+
 def test_generic_kernel_matches_vector_kernel():
-    pool, lib = _pool(), _lib()
-    x, q, a = _t(rnd(31, 4, 45, 256)), _t(rnd(32, 64, 4, scale=0.3)), _t(rnd(33, 64, 1, scale=0.3))
-    out1, al1, _, _ = pool.double_mha(x, q, a)
-    assert b"vec<" in lib.dasv_debug_last_variant()
-    lib.dasv_debug_set_tuning(0, 0, 0, 1, 0)
+    from doubleattentionspeakerverification_amd import _lib as libmod
+    dbg = libmod.debug_probe()
+    x, q, a = _t(rnd(31, 4, 45, 256)), _t(rnd(32, 64, 4, scale=0.3)), _t(rnd(33, 64, 1, scale=0.3)).view(-1)
+    out1, al1, v1 = _dbg_double_mha(dbg, x, q, a)
+    assert "vec<" in v1
+    dbg.dasv_debug_set_tuning(0, 0, 0, 1, 0)
     try:
-        out2, al2, _, _ = pool.double_mha(x, q, a)
-        assert b"generic" in lib.dasv_debug_last_variant()
+        out2, al2, v2 = _dbg_double_mha(dbg, x, q, a)
+        assert "generic" in v2
     finally:
-        lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
+        dbg.dasv_debug_set_tuning(0, 0, 0, 0, 0)
     np.testing.assert_allclose(out1.cpu().numpy(), out2.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(al1.cpu().numpy(), al2.cpu().numpy(), atol=1e-6)
+    # the product library exports no knob at all
+    assert not hasattr(_lib(), "dasv_debug_set_tuning") and not hasattr(_lib(), "dasv_debug_read_floor")
 
 
 @pytest.mark.parametrize("nw,wpu,rows", [(4, 1, 0), (4, 2, 8), (4, 4, 2), (8, 8, 0), (8, 2, 0), (2, 1, 8), (1, 1, 0), (4, 4, 8)])
 def test_workgroup_shapes_agree(nw, wpu, rows):
     """Every (waves per workgroup, waves per head) split must give the same answer."""
-    pool, lib = _pool(), _lib()
+    from doubleattentionspeakerverification_amd import _lib as libmod
+    dbg = libmod.debug_probe()
     x, q, a = rnd(41, 3, 150, 512), rnd(42, 64, 8, scale=0.3), rnd(43, 64, 1, scale=0.3)
     f = oracle.dmha_closed(x, q, a)
-    lib.dasv_debug_set_tuning(nw, wpu, 0, 0, rows)
+    dbg.dasv_debug_set_tuning(nw, wpu, 0, 0, rows)
     try:
-        out, al, hw, _ = pool.double_mha(_t(x), _t(q), _t(a))
+        out, al, _ = _dbg_double_mha(dbg, _t(x), _t(q), _t(a).view(-1))
     finally:
-        lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
+        dbg.dasv_debug_set_tuning(0, 0, 0, 0, 0)
     np.testing.assert_allclose(out.cpu().numpy(), f["out"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(al.cpu().numpy(), f["align"], atol=1e-6)
 
@@ -388,7 +409,7 @@ def test_nhwc_map_is_pooled_in_place_like_the_transposed_frames(B, T, C, H):
         if tag == "map":
             x = h4.clone().requires_grad_(True)
             out, al = mod.pool_map(x, head_keep=_t(keep, torch.bool), lengths=_t(lens, torch.int32), want_align=True)
-            assert "nhwc" in _lib().dasv_debug_last_variant().decode()
+            assert "nhwc" in _lib().dasv_dmha_last_variant().decode()
         else:
             x = _t(frames).requires_grad_(True)
             out, al = mod(x, head_keep=_t(keep, torch.bool), lengths=_t(lens, torch.int32))

@@ -43,7 +43,7 @@ def main():
     lib.dasv_dmha_fwd.argtypes = [ci] + [vp] * 10 + [vp, csz, ci, ci, ci, ci, c64, c64, vp]
     lib.dasv_debug_set_stamps.argtypes = [vp]
     lib.dasv_debug_set_tuning.argtypes = [ci] * 5
-    lib.dasv_debug_last_variant.restype = ctypes.c_char_p
+    lib.dasv_dmha_last_variant.restype = ctypes.c_char_p
     B, T, D, H = (int(v) for v in args.shape.split(","))
     dh = D // H
     dev = torch.device("cuda:0")
@@ -69,7 +69,7 @@ def main():
                                ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh, T * D, D, stream)
         assert rc == 0, rc
         import re
-        mm = re.search(r"upw=(\d+)", lib.dasv_debug_last_variant().decode())
+        mm = re.search(r"upw=(\d+)", lib.dasv_dmha_last_variant().decode())
         GRID[0] = 8 * ((B + 7) // 8) * (H // int(mm.group(1))) if mm else nwg_max
     for i in range(20):
         launch(i, None)
@@ -109,7 +109,7 @@ def main():
             d = (s[ok, k + 1] - s[ok, k]) * 0.01
             iv.append((np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max(), ok.sum()) if ok.any() else (np.nan,) * 5)
         ivals.append(iv)
-    print("variant:", lib.dasv_debug_last_variant().decode(), " workgroups:", int(used.sum()))
+    print("variant:", lib.dasv_dmha_last_variant().decode(), " workgroups:", int(used.sum()))
     print("%-18s %8s %8s %8s %6s   (us since first workgroup start; median over stamped launches)" % ("phase", "min", "median", "max", "n"))
     agg = np.array(agg, dtype=np.float64)
     for k, nm in enumerate(names):

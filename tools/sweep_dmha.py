@@ -96,7 +96,7 @@ def main():
         except AssertionError as e:
             print("(%d,%d,%d,%d) failed rc=%s" % (nw, wpu, pad, rows, e))
             continue
-        var = lib.dasv_debug_last_variant().decode()
+        var = lib.dasv_dmha_last_variant().decode()
         print("%-30s %10.2f %10.2f %9.0f %8.1f%%   %s" % ((nw, wpu, pad, rows), med, mn, abytes / med / 1e3, abytes / med / 1e3 / 80.0, var))
     lib.dasv_debug_set_tuning(0, 0, 0, 0, 0)
 
