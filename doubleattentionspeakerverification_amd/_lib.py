@@ -66,6 +66,9 @@ SIGNATURES = {
     "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_bwd_nhwc_f32": (c_int, [c_void_p] * 12 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_last_variant": (ctypes.c_char_p, []),
+    "dasv_amsoftmax_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dasv_amsoftmax_fwd": (c_int, [c_void_p] * 10 + [c_size_t, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
+    "dasv_amsoftmax_bwd": (c_int, [c_void_p] * 13 + [c_size_t, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p]),
 }
 
 # the developer surface: exported by libdasv_hip_dbg.so only (include/dasv_hip.h, #ifdef DASV_DEBUG)

@@ -447,7 +447,18 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     const int frow = lane & 15, fq = lane >> 4;
     const int tile = xcd * p.tiles_per_xcd + idx;
     if (idx >= p.tiles_per_xcd || tile >= p.mtiles * p.ntiles) return;
+#ifndef DASV_CONV_ORDER
+#define DASV_CONV_ORDER 0
+#endif
+#if DASV_CONV_ORDER == 1     // experiment: pixel tiles fastest (an XCD sweeps the pixel tiles of one weight slab set)
+    const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
+#elif DASV_CONV_ORDER == 2   // experiment: groups of 4 pixel tiles x all channel tiles
+    const int grp = tile / (4 * p.ntiles), rem = tile - grp * 4 * p.ntiles;
+    const int gsz = min(4, p.mtiles - grp * 4);
+    const int nt = rem / gsz, mt = grp * 4 + rem - nt * gsz;
+#else
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+#endif
     const int m0 = mt * TBM, n0 = nt * CBN;
     DASV_STAMP(0);
 

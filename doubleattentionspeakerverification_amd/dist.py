@@ -173,25 +173,28 @@ class FlatGradReducer:
                     self._launch(bi)
         finally:
             self._in_finish = False
-        if self._cold_fired and self.world > 1:
+        # the cold buffers are reduced whenever they exist — not only when THIS rank saw one of their parameters fire: a gradient
+        # that appears on one rank only (data-dependent graph) would otherwise make the ranks issue different collectives
+        cold = bool(self._cold_bufs) and self.world > 1
+        if cold:
             for buf in self._cold_bufs:
                 self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
         self._works = []
-        self._armed = False
+        was_armed, self._armed = self._armed, False
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
-            if self._cold_fired:
+            if cold:
                 for buf in self._cold_bufs:
                     buf.mul_(1.0 / self.world)
-        self._retire_unfired()
+        if was_armed:      # finish() without arm() saw no backward: nothing may be retired on its evidence
+            self._retire_unfired()
 
     def zero(self):
         self.flat.zero_()
-        if any(self._fired[i] for i in self._cold):
-            for buf in self._cold_bufs:
-                buf.zero_()
+        for buf in self._cold_bufs:
+            buf.zero_()
         self._fired = [False] * len(self.params)
 
     def hide_unused(self):
@@ -231,6 +234,7 @@ class DataParallelTrainer:
         else:
             raise ValueError(optimizer)
         self.criterion = nn.CrossEntropyLoss()
+        self.fused_loss = True     # use net.forward_loss (fused AM-softmax + CE head) when the model has one
         self._micro = 0
 
     def broadcast_state(self):
@@ -250,9 +254,15 @@ class DataParallelTrainer:
         if last:
             self.reducer.arm()
         dev_type = "cuda" if x.is_cuda else "cpu"
+        fused = getattr(self.net, "forward_loss", None) if self.fused_loss else None
         with torch.autocast(dev_type, dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
-            costh, logits = self.net(x, label=labels, step=step)
-        loss = self.criterion(logits.float(), labels)
+            if fused is not None:
+                # AM-softmax + cross-entropy as one fused head (csrc/amsoftmax.hip): no [B,N] logits, one-hot or log-softmax
+                loss, costh = fused(x, labels, step)
+            else:
+                costh, logits = self.net(x, label=labels, step=step)
+        if fused is None:
+            loss = self.criterion(logits.float(), labels)
         loss.backward()
         if last:
             self.reducer.finish()

@@ -88,6 +88,10 @@ class SpeakerClassifier(nn.Module):
     def forward(self, x, label=None, step=0):
         return self.predictionLayer(self.preLayer(self.getEmbedding(x)), label, step)
 
+    def forward_loss(self, x, label, step=0):
+        """(loss, costh): forward() followed by train.py:219's CrossEntropyLoss in one fused head (loss.AMSoftmax.fused_loss)."""
+        return self.predictionLayer.fused_loss(self.preLayer(self.getEmbedding(x)).float(), label, step)
+
 
 __all__ = ["SpeakerClassifier", "new_parameter", "Attention", "HeadAttention", "innerKeyValueAttention",
            "MultiHeadAttention", "DoubleMHA", "getVGG3LOutputDimension", "getVGG4LOutputDimension",

@@ -301,6 +301,27 @@ int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att,
                            float* grad_query, float* grad_att, void* workspace, size_t workspace_bytes, int B, int T, int F,
                            int C, int H, dasv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * AM-softmax head + cross-entropy (loss.py:37-52 AMSoftmax.forward and train.py:219 nn.CrossEntropyLoss), forward and backward:
+ * cos(theta)[b][n] = <x_b, W_n> / (max(|x_b|, 1e-12) max(|W_n|, 1e-12)) as one fp32 product with the norms taken from the same
+ * tiles, the margin by a label compare on the device (the reference builds a [B,N] one-hot on the HOST and copies it back,
+ * loss.py:46-48), logits = scale * (cos - margin * onehot / (1 + alpha)) (alpha: loss.py:28-35, 0 without annealing), and —
+ * when loss / lse are given — the mean cross-entropy of the logits with the row log-sum-exps, without a [B,N] softmax.
+ *   x [B,E], W [E,N], label [B] int64;  costh [B,N] (always written), logits [B,N] or NULL, loss [1] + lse [B] or both NULL,
+ *   xinv [B], winv [N] (the reciprocal clamped norms, saved for backward).
+ * Backward: gx [B,E], gW [E,N] (OVERWRITTEN) from either the fused loss (lse given; g_loss [1] = upstream gradient of the loss
+ * or NULL for 1) or upstream gradients of the two module outputs (lse NULL; g_costh / g_logits [B,N], either may be NULL).
+ * Deterministic (fixed-order reductions).  workspace: dasv_amsoftmax_workspace_bytes(), no init needed.
+ * ------------------------------------------------------------------------ */
+size_t dasv_amsoftmax_workspace_bytes(int B, int E, int N);
+int dasv_amsoftmax_fwd(const float* x, const float* W, const int64_t* label, float* costh, float* logits, float* loss, float* lse,
+                       float* xinv, float* winv, void* workspace, size_t workspace_bytes, int B, int E, int N, float margin,
+                       float scale, float alpha, dasv_stream_t stream);
+int dasv_amsoftmax_bwd(const float* x, const float* W, const int64_t* label, const float* costh, const float* lse, const float* xinv,
+                       const float* winv, const float* g_loss, const float* g_costh, const float* g_logits, float* gx, float* gW,
+                       void* workspace, size_t workspace_bytes, int B, int E, int N, float margin, float scale, float alpha,
+                       dasv_stream_t stream);
+
 /* name of the kernel variant the last dasv_dmha_fwd call on this thread selected (introspection: smoke tests and bench.py
  * record it; e.g. "vec<dtype=0,G=16,NI=1,R=4> nw=8 wpu=4 upw=2 lds=11200") */
 const char* dasv_dmha_last_variant(void);

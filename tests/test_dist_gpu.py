@@ -32,6 +32,9 @@ def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
         x = torch.from_numpy(rs.standard_normal((4, 61, 80)).astype(np.float32)).to(dev)
         y = torch.tensor([3, 9, 9, 60], device=dev)
         trainer = DataParallelTrainer(net, lr=0.05, weight_decay=0.0, optimizer="SGD", bucket_bytes=8 << 20)
+        # the reducer is what is tested: same head arithmetic as the plain step below (the fused AM-softmax + CE head agrees with
+        # it to ~1e-7, tests/test_model_gpu.py, but fc2.bias's gradient behind train-mode BatchNorm is pure rounding residue)
+        trainer.fused_loss = False
         assert len(trainer.reducer.buckets) >= 4
         trainer.reducer.world = 2                    # pretend: forces the collective path; the 1-rank sum is the identity
         launched = []

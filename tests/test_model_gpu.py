@@ -389,6 +389,8 @@ def test_data_parallel_trainer_single_rank_matches_plain_optimizer_step():
     opt.step()
     # trainer (accum = 2), same masks via a patched forward
     tr = DataParallelTrainer(net_a, lr=1e-3, weight_decay=1e-3, optimizer="Adam", accum=2, bucket_bytes=1 << 16)
+    tr.fused_loss = False      # same head arithmetic as the plain step: Adam's first update is sign-like, so rounding-level
+    #                            gradient differences (the fused head agrees to ~1e-7) would show as 2 * lr
     it = iter(keep)
     net_a.forward = lambda x, label=None, step=0: fwd(net_a, x, label, next(it))
     for x, y in zip(xs, ys):
@@ -955,3 +957,71 @@ def test_packed_activation_chain_matches_the_fp32_chain_and_the_oracle(B, T):
         z_f = hc.conv3x3_bias_relu(hc.conv3x3_bias_relu(pf, fe.conv21.weight, fe.conv21.bias, None, "split8"),
                                    fe.conv22.weight, fe.conv22.bias, None, "split8")
         assert float((z_p - z_f).abs().max()) < 2e-5 * float(z_f.abs().max())
+
+
+@pytest.mark.parametrize("ann", [False, True])
+def test_amsoftmax_hip_head_matches_golden_g5(ann):
+    """Fixture G5 (the reference's AMSoftmax + CrossEntropyLoss, loss.py:37-52 / train.py:219, annealing on and off, steps 0 ... 1e6)
+    against the hand-written head (csrc/amsoftmax.hip): the module form (costh, logits -> torch CE) and the fused form
+    (fused_loss: no logits, no one-hot, no log-softmax) — values and both gradients."""
+    from doubleattentionspeakerverification_amd.loss import AMSoftmax
+    g = load_golden("g5_amsoftmax")
+    tag = "ann" if ann else "plain"
+    head = AMSoftmax(24, 37, m=0.4, s=30.0, annealing=ann).to(DEV)
+    with torch.no_grad():
+        head.W.copy_(torch.from_numpy(g[tag + "_W"]))
+    lab = torch.from_numpy(g["label"]).to(DEV)
+    for step in (0, 100, 5000, 1000000):
+        k = "%s_s%d_" % (tag, step)
+        for fused in (False, True):
+            x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+            head.W.grad = None
+            if fused:
+                loss, costh = head.fused_loss(x, lab, step)
+            else:
+                costh, logits = head(x, lab, step)
+                np.testing.assert_allclose(logits.detach().cpu().numpy(), g[k + "logits"], rtol=1e-5, atol=2e-5)
+                loss = torch.nn.functional.cross_entropy(logits, lab)
+            loss.backward()
+            np.testing.assert_allclose(costh.detach().cpu().numpy(), g[k + "costh"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(float(loss.detach()), float(g[k + "loss"]), rtol=2e-6)
+            np.testing.assert_allclose(x.grad.cpu().numpy(), g[k + "grad_x"], rtol=1e-4, atol=1e-6 * np.abs(g[k + "grad_x"]).max() + 1e-7)
+            np.testing.assert_allclose(head.W.grad.cpu().numpy(), g[k + "grad_W"], rtol=1e-4, atol=1e-6 * np.abs(g[k + "grad_W"]).max() + 1e-7)
+        assert abs(head.getAnnealedFactor(step) - float(g[k + "factor"])) < 1e-12
+
+
+def test_amsoftmax_hip_head_default_size_vs_float64():
+    """The default head (emb 400 -> 5994 speakers, B = 64: tiles with ragged edges in every dimension) against the reference's op
+    sequence in float64 on the CPU: loss, costh, gradients; the fused and the module form agree; a label at the last column."""
+    from doubleattentionspeakerverification_amd.loss import AMSoftmax
+    torch.manual_seed(3)
+    B, E, N = 64, 400, 5994
+    head = AMSoftmax(E, N, m=0.4, s=30.0).to(DEV)
+    x0 = torch.randn(B, E) * 3.0
+    lab = torch.randint(0, N, (B,))
+    lab[0], lab[1] = N - 1, 0
+    Wd = head.W.detach().cpu().double()
+    xd = x0.double().requires_grad_(True)
+    Wd.requires_grad_(True)
+    rows = xd / xd.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    cols = Wd / Wd.norm(dim=0, keepdim=True).clamp(min=1e-12)
+    costh_ref = rows @ cols
+    logits_ref = 30.0 * (costh_ref - 0.4 * torch.nn.functional.one_hot(lab, N).double())
+    loss_ref = torch.nn.functional.cross_entropy(logits_ref, lab)
+    loss_ref.backward()
+    res = {}
+    for fused in (True, False):
+        x = x0.to(DEV).requires_grad_(True)
+        head.W.grad = None
+        if fused:
+            loss, costh = head.fused_loss(x, lab.to(DEV), 0)
+        else:
+            costh, logits = head(x, lab.to(DEV), 0)
+            loss = torch.nn.functional.cross_entropy(logits, lab.to(DEV))
+        loss.backward()
+        res[fused] = (float(loss.detach()), costh.detach().cpu(), x.grad.cpu(), head.W.grad.cpu())
+        assert abs(res[fused][0] - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
+        assert float((res[fused][1].double() - costh_ref.detach()).abs().max()) < 2e-6
+        assert float((res[fused][2].double() - xd.grad).abs().max()) <= 2e-5 * float(xd.grad.abs().max())
+        assert float((res[fused][3].double() - Wd.grad).abs().max()) <= 2e-5 * float(Wd.grad.abs().max())
+    assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-5 * float(res[False][2].abs().max())

@@ -17,14 +17,20 @@ from doubleattentionspeakerverification_amd import _lib, conv as hc  # noqa: E40
 
 vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 old = ctypes.CDLL(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "_diag", "libdasv_r2conv.so"))
+# AB_SAME_ABI=1: the reference library is a build of the CURRENT sources (range records in the ABI): it shares the packed input,
+# weights and records with the in-tree library and only the convolution launch differs
+SAME = os.environ.get("AB_SAME_ABI") == "1"
 old.dasv_conv3x3_bias_relu_x8_nhwc.restype = ci
-old.dasv_conv3x3_bias_relu_x8_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, sz, ci, ci, ci, ci, ci, ci, vp]
-old.dasv_maxpool2x2_ceil_x8_nhwc.restype = ci
-old.dasv_maxpool2x2_ceil_x8_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, vp]
-old.dasv_conv3x3_pack_weights_x8.restype = ci
-old.dasv_conv3x3_pack_weights_x8.argtypes = [vp, vp, vp, ci, ci, vp]
-old.dasv_conv3x3_packed_weight_bytes_x8.restype = sz
-old.dasv_conv3x3_packed_weight_bytes_x8.argtypes = [ci, ci]
+if SAME:
+    old.dasv_conv3x3_bias_relu_x8_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, sz, ci, ci, ci, ci, ci, ci, vp]
+else:
+    old.dasv_conv3x3_bias_relu_x8_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, sz, ci, ci, ci, ci, ci, ci, vp]
+    old.dasv_maxpool2x2_ceil_x8_nhwc.restype = ci
+    old.dasv_maxpool2x2_ceil_x8_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    old.dasv_conv3x3_pack_weights_x8.restype = ci
+    old.dasv_conv3x3_pack_weights_x8.argtypes = [vp, vp, vp, ci, ci, vp]
+    old.dasv_conv3x3_packed_weight_bytes_x8.restype = sz
+    old.dasv_conv3x3_packed_weight_bytes_x8.argtypes = [ci, ci]
 new = _lib.load()
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
@@ -39,13 +45,14 @@ for name, cin, cout, H, W, ypk in LAYERS:
     w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, device=dev) * 0.1
     # old library: its own packed input and weights
-    xo = torch.empty(B, H, W, cin, device=dev)
-    assert old.dasv_maxpool2x2_ceil_x8_nhwc(xf.data_ptr(), xo.data_ptr(), B, 2 * H, 2 * W, cin, st) == 0
-    n16 = cout * 9 * cin * 2
-    who = torch.empty(n16, dtype=torch.uint8, device=dev)
-    wlo = torch.empty(max(n16, old.dasv_conv3x3_packed_weight_bytes_x8(cout, cin)), dtype=torch.uint8, device=dev)
-    assert old.dasv_conv3x3_pack_weights_x8(w.data_ptr(), who.data_ptr(), wlo.data_ptr(), cout, cin, st) == 0
     yo = torch.empty(B, H, W, cout, device=dev)
+    if not SAME:
+        xo = torch.empty(B, H, W, cin, device=dev)
+        assert old.dasv_maxpool2x2_ceil_x8_nhwc(xf.data_ptr(), xo.data_ptr(), B, 2 * H, 2 * W, cin, st) == 0
+        n16 = cout * 9 * cin * 2
+        who = torch.empty(n16, dtype=torch.uint8, device=dev)
+        wlo = torch.empty(max(n16, old.dasv_conv3x3_packed_weight_bytes_x8(cout, cin)), dtype=torch.uint8, device=dev)
+        assert old.dasv_conv3x3_pack_weights_x8(w.data_ptr(), who.data_ptr(), wlo.data_ptr(), cout, cin, st) == 0
     # new library
     recs = hc.new_ranges(dev, 3)
     recs[0] = hc.range_of(xf)
@@ -56,6 +63,9 @@ for name, cin, cout, H, W, ypk in LAYERS:
     yn = torch.empty(B, H, W, cout, device=dev)
 
     def run_old():
+        if SAME:
+            return old.dasv_conv3x3_bias_relu_x8_nhwc(xn.data_ptr(), 1, recs[1].data_ptr(), whn.data_ptr(), wln.data_ptr(), b.data_ptr(),
+                                                      yo.data_ptr(), ypk, recs[2].data_ptr(), None, 0, B, H, W, cin, cout, 1, st)
         return old.dasv_conv3x3_bias_relu_x8_nhwc(xo.data_ptr(), 1, who.data_ptr(), wlo.data_ptr(), b.data_ptr(), yo.data_ptr(), ypk, None, 0,
                                                   B, H, W, cin, cout, 1, st)
 
