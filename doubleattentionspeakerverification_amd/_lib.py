@@ -48,6 +48,7 @@ SIGNATURES = {
     "dasv_maxpool2x2_ceil_ragged_x8_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
+    "dasv_conv3x3_masked_x8_nhwc": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),

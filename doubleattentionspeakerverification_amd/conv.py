@@ -21,9 +21,12 @@ __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights"
            "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of"]
 
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
-# "split8": fp32-grade forward on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8);
-# it needs fp16's exponent range on the operands, so gradients keep the split-bf16 kernel
+# "split8": fp32-grade on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8).  Its
+# operand planes have fp16's / e4m3's exponent range, which is why round 2 kept gradients on the split-bf16 kernel; with every
+# tensor scaled by its range record the DATA gradient runs in split8 too (DGRAD_MODE); the weight gradient (its own kernel,
+# csrc/conv3x3_wgrad.hip) stays split-bf16.
 BACKWARD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split"}
+DGRAD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split8"}
 _PACK_KIND = {"split": 0, "bf16": 0, "fp16": 1, "split8": 2}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
 
@@ -150,9 +153,15 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
         x_rec = range_of(x)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if mode == "split8":
-            if mask is not None:
-                raise RuntimeError("split8 is a forward mode (no masked data-gradient form)")
+        if mode == "split8" and mask is not None:
+            rows = lib.dasv_conv3x3_colsum_rows(B, H, W) if colsum is not None else 0
+            part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
+            rc = lib.dasv_conv3x3_masked_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
+                                                 None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
+                                                 B, H, W, cin, cout, stream)
+            if part is not None and rc == 0:
+                colsum["gb"] = part.sum(dim=0)
+        elif mode == "split8":
             nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
             rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 0, x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
@@ -232,6 +241,11 @@ class _ConvReLUFn(torch.autograd.Function):
         padded = (cin_x, cout_p) != (cin, cout)
         gx = None
         bmode = BACKWARD_MODE[ctx.mode]
+        dmode = DGRAD_MODE[ctx.mode] if x.shape[3] <= 80 else bmode       # (the split8 form exists in the window kernel only)
+        # split8 data gradient: the incoming gradient's range record rides on the tensor when a kernel of this library produced it
+        # (the layer above's data gradient, the pool's backward); otherwise one pass over it measures it
+        g_rec = getattr(gy, "_dasv_rec", None) if dmode == "split8" else None
+        gx_rec = new_ranges(x.device)[0] if dmode == "split8" else None
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if want_x and g.dtype == torch.float32:
@@ -245,14 +259,16 @@ class _ConvReLUFn(torch.autograd.Function):
                 wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, n_out - cin, 0, cout_p - cout))
             wt = wt.transpose(0, 1).flip(2, 3).contiguous()
             pk = PackedConvWeights()
-            hi, lo = pk.get(wt, bmode)
+            hi, lo = pk.get(wt, dmode)
             if n_out == cin_x:
                 # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
                 # backward is applied in this kernel's epilogue
-                gx = _launch(g, hi, lo, None, cin_x, bmode, relu=0, mask=x if ctx.mask_input_grad else None,
-                             colsum=ctx.link_out if ctx.mask_input_grad else None)
+                gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
+                             colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec)
+                if gx_rec is not None:
+                    gx._dasv_rec = gx_rec
             else:
-                gx = _launch(g, hi, lo, None, n_out, bmode, relu=0)[:, :cin_x].contiguous(memory_format=torch.channels_last)
+                gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec)[:, :cin_x].contiguous(memory_format=torch.channels_last)
                 if ctx.mask_input_grad:
                     gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
             want_x = False
@@ -457,6 +473,9 @@ class _MaxPoolFn(torch.autograd.Function):
             else:
                 rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
+        rec = getattr(gy, "_dasv_rec", None)
+        if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)
+            gx._dasv_rec = rec
         return gx, None, None, None, None
 
 

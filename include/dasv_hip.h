@@ -188,6 +188,12 @@ int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, c
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
                              float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_colsum_rows(int B, int H, int W);
+/* The same in the split8 mode (mode 3 above), which the range records make usable for GRADIENTS too: x (the gradient at the upper
+ * layer's output, any magnitude — 1e-8 is common) is scaled into the operand planes' range by its record, the transposed weights
+ * per channel.  x_range required, y_range optional (receives max |y|: the next layer down scales ITS gradient by it). */
+int dasv_conv3x3_masked_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const float* mask,
+                                float* y, uint32_t* y_range, float* colsum_partial, int B, int H, int W, int Cin, int Cout,
+                                dasv_stream_t stream);
 
 /* Two layers in one launch: y = relu(conv3x3(relu(conv3x3_1ch(mel) + b1)) + bias) — the first block of the VGG front-end
  * (`F.relu(self.conv12(F.relu(self.conv11(x))))`, CNNs.py:38-39 / 72-73).  The one-channel layer's activations are
@@ -248,6 +254,7 @@ int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, const uint32_t* x_range,
  * arg-max is recomputed (first maximum in row-major window order wins, as ATen does).  Replaces autograd's max_pool2d
  * backward for CNNs.py:40,44,48 / 74,78,82,86. */
 int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, int B, int H, int W, int C, dasv_stream_t stream);
+/* (the scattered gradient's range record is gy's: max |gx| <= max |gy|, a bound, which is what a consumer's scale needs) */
 /* Same, for x = a ReLU's output (`F.relu(self.convX2(..))` feeding the pool): the gradient is also passed through that
  * ReLU (zero where the window maximum is not > 0), which saves the separate mask pass over [B,H,W,C]. */
 int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, float* colsum_partial, int B, int H, int W,
