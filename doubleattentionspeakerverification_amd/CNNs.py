@@ -19,7 +19,9 @@ max-pool), the last map sliced back: no second convolution backend on the path. 
            runs in "split"
   "split"  fp32-grade accuracy on the bf16 matrix cores (operands split hi + lo, 3 MFMAs per product, ~5e-6)
   "bf16"   operands rounded to bf16 (one MFMA per product)
-  "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands)
+  "fp16"   operands rounded to fp16 (one MFMA per product, 11 mantissa bits; gradients use bf16 operands); in inference the
+           activations between the layers are then STORED as fp16 too (`half_activations`: 2 bytes per element, scaled per tensor
+           by its range record so that fp16's range is never the limit — BASELINE config 3 "bf16" / config 5 "fp16 MFMA path")
   "torch"  PyTorch-ROCm / MIOpen for every layer (comparison runs only)
 Under `torch.autocast` the HIP kernels run with bf16 / fp16 operands (the autocast dtype), fp32 accumulation and fp32
 activations.
@@ -72,6 +74,8 @@ class _VGG(nn.Module):
         self.fuse_first_block = False
         # inference: activations between the split8 layers in the consumer's operand form (conv.conv3x3_x8); same results
         self.packed_activations = True
+        # inference in the fp16-operand mode: activations between the layers as fp16 tensors (conv.conv3x3_f16)
+        self.half_activations = True
         self._packed = {}
 
     def _mode(self):
@@ -118,7 +122,9 @@ class _VGG(nn.Module):
         activations between the layers are then written once in the consumer's operand form (conv.conv3x3_x8).  Not for small
         batches: a packed output is written by the convolution's own epilogue, so those launches could not divide their channel
         slabs over workgroups (split-K) — the fp32 chain is faster there (single utterances: train.py:117-133)."""
-        if self._mode() != "split8" or self.fuse_first_block or fdim > 80 or self.conv11.out_channels % 64 != 0:
+        mode = self._mode()
+        if (mode != "split8" and not (mode == "fp16" and self.half_activations)) or self.fuse_first_block or fdim > 80 \
+                or self.conv11.out_channels % 64 != 0:
             return False
         if batch is not None:
             from . import _lib
@@ -171,6 +177,33 @@ class _VGG(nn.Module):
             rh = ry
         return h
 
+    def _forward_map_f16(self, x):
+        """The same chain with HALF-PRECISION tensors between the layers (fp16-operand mode, inference): conv11 -> f16 -> conv12 ->
+        f16 -> pool -> f16 -> ... -> convN2 -> f16 -> last pool -> fp32 map.  Every tensor holds v * 2^E, E from its range record
+        (conv.conv3x3_f16); values are rounded to fp16 once per layer — the rounding the fp16 operands apply anyway."""
+        dev = x.device
+        recs = _hipconv.new_ranges(dev, 1 + 3 * self.n_blocks)
+        r = iter(recs)
+        rx = next(r)
+        _lib = _hipconv._lib
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dasv_range_absmax_f32")
+        rh = next(r)
+        h = _hipconv.conv3x3_c1_bias_relu(x, self.conv11.weight, self.conv11.bias, pack=2, x_rec=rx, y_rec=rh)
+        for blk in range(1, self.n_blocks + 1):
+            c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
+            if blk > 1:
+                ry = next(r)
+                h = _hipconv.conv3x3_f16(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_f16=True, y_f16=True, x_rec=rh, y_rec=ry)
+                rh = ry
+            ry = next(r)
+            h = _hipconv.conv3x3_f16(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_f16=True, y_f16=True, x_rec=rh, y_rec=ry)
+            rh, ry = ry, next(r)
+            h = _hipconv.maxpool2x2_ceil(h, pack=2 if blk < self.n_blocks else False, x_rec=rh, y_rec=ry)
+            rh = ry
+        return h
+
     def _hip_front(self, x):
         """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
         features themselves do not need a gradient."""
@@ -190,8 +223,11 @@ class _VGG(nn.Module):
         B, T, Fdim = paddedInputTensor.shape
         hip = self._hip_front(paddedInputTensor)
         grad = torch.is_grad_enabled()
-        if hip and not grad and self.packed_activations and self._packed_chain_ok(Fdim, B, T):
+        if hip and not grad and self.packed_activations and self._mode() == "split8" and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_packed(paddedInputTensor)
+        if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
+                and self._packed_chain_ok(Fdim, B, T):
+            return self._forward_map_f16(paddedInputTensor)
         fused_first = False
         # split8: one range record per tensor (see _forward_map_packed); rh = the record of h, None where h has none
         x8 = hip and self._mode() == "split8"

@@ -18,7 +18,7 @@ from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu", "conv3x3_x8",
-           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of"]
+           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of", "conv3x3_f16"]
 
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
 # "split8": fp32-grade on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8).  Its
@@ -96,7 +96,7 @@ class PackedConvWeights:
         if pad is not None and tuple(pad) == (cin, cout):
             pad = None
         key = (weight.data_ptr(), weight._version, weight.device, kind, pad,
-               None if (bias is None or (kind != 2 and pad is None)) else (bias.data_ptr(), bias._version))
+               None if (bias is None or (kind == 0 and pad is None)) else (bias.data_ptr(), bias._version))
         if not (cacheable and key == self.key and self.owner is not None and self.owner() is weight):
             lib = _lib.load()
             w = weight.detach().contiguous(memory_format=torch.contiguous_format).float()
@@ -109,7 +109,7 @@ class PackedConvWeights:
                 if bias is not None:
                     self.bias = bias = torch.nn.functional.pad(bias.detach().float(), (0, cout_p - cout))
                 cout, cin = cout_p, cin_p
-            n = lib.dasv_conv3x3_packed_weight_bytes(cout, cin)
+            n = max(lib.dasv_conv3x3_packed_weight_bytes(cout, cin), lib.dasv_conv3x3_packed_weight_bytes_f16(cout, cin))
             nlo = max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cout, cin))   # the e4m3 plane carries its scale bytes behind it
             if not cacheable or self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
                 # (weights that are not a leaf Parameter — DataParallel replicas, functional weights — get fresh planes per call:
@@ -123,7 +123,8 @@ class PackedConvWeights:
                     rc = lib.dasv_conv3x3_pack_weights_x8(w.data_ptr(), None if b is None else b.data_ptr(), self.hi.data_ptr(),
                                                           self.lo.data_ptr(), cout, cin, stream)
                 elif kind == 1:
-                    rc = lib.dasv_conv3x3_pack_weights_f16(w.data_ptr(), self.hi.data_ptr(), cout, cin, stream)
+                    b = None if bias is None else bias.detach().float().contiguous()
+                    rc = lib.dasv_conv3x3_pack_weights_f16(w.data_ptr(), None if b is None else b.data_ptr(), self.hi.data_ptr(), cout, cin, stream)
                 else:
                     rc = lib.dasv_conv3x3_pack_weights(w.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(), cout, cin, stream)
             _lib.check(rc, "dasv_conv3x3_pack_weights")
@@ -342,11 +343,17 @@ def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
     B, H, W = x.shape
     cout = weight.shape[0]
     x = x.contiguous()
-    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((B, cout, H, W), dtype=torch.float16 if pack == 2 else torch.float32, device=x.device, memory_format=torch.channels_last)
     wp, bp = weight.detach().contiguous().data_ptr(), None if bias is None else bias.detach().data_ptr()
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if pack:
+        if pack == 2:      # a half-precision tensor for the fp16 activation chain (conv3x3_f16)
+            if y_rec is None:
+                raise RuntimeError("a half-precision output needs a range record (conv.new_ranges)")
+            x_rec = range_of(x) if x_rec is None else x_rec
+            rc = lib.dasv_conv3x3_c1_bias_relu_f16_nhwc(x.data_ptr(), x_rec.data_ptr(), wp, bp, y.data_ptr(), y_rec.data_ptr(), B, H, W,
+                                                        cout, 1, stream)
+        elif pack:
             if y_rec is None:
                 raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
             x_rec = range_of(x) if x_rec is None else x_rec
@@ -399,6 +406,39 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_r
     return y
 
 
+def conv3x3_f16(x, weight, bias, packed=None, x_f16=False, y_f16=False, x_rec=None, y_rec=None):
+    """Inference-only relu(conv2d(x, weight, bias, padding 1)) with fp16 operands on HALF-PRECISION activation tensors.
+
+    A half-precision tensor is what the fp32 channels_last tensor would be with 2-byte elements: [B,H,W,C] fp16 in NHWC memory
+    (here a torch.float16 tensor of logical shape [B,C,H,W], channels_last), holding v * 2^E with E in the tensor's range record
+    (conv.new_ranges) — half the HBM traffic of every layer, and the convolution's window staging becomes a copy.  Producers:
+    this function (y_f16), conv3x3_c1_bias_relu(pack=2), maxpool2x2_ceil on a half-precision input."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    want = torch.float16 if x_f16 else torch.float32
+    if not x.is_cuda or x.dtype != want or not exact(cin, cout) or W > 80 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("conv3x3_f16: unsupported shape/dtype/layout %s %s" % (tuple(x.shape), x.dtype))
+    packed = packed or PackedConvWeights()
+    hi, _ = packed.get(weight, "fp16", bias)
+    if x_rec is None:
+        if x_f16:
+            raise RuntimeError("a half-precision input needs the range record its producer filled")
+        x_rec = range_of(x)
+    if y_f16 and y_rec is None:
+        raise RuntimeError("a half-precision output needs a range record (conv.new_ranges)")
+    y = torch.empty((B, cout, H, W), dtype=torch.float16 if y_f16 else torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        nws = 0 if y_f16 else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        rc = lib.dasv_conv3x3_bias_relu_f16_nhwc(x.data_ptr(), int(x_f16), x_rec.data_ptr(), hi.data_ptr(),
+                                                 None if bias is None else bias.detach().data_ptr(), y.data_ptr(), int(y_f16),
+                                                 None if y_rec is None else y_rec.data_ptr(), None if ws is None else ws.data_ptr(), nws,
+                                                 B, H, W, cin, cout, 1, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_f16_nhwc")
+    return y
+
+
 def maxpool2x2_ceil(x, pack=False, x_rec=None, y_rec=None):
     """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W].
     x_rec / y_rec (together): the pooled map's range record is its input's.
@@ -407,6 +447,19 @@ def maxpool2x2_ceil(x, pack=False, x_rec=None, y_rec=None):
     B, C, H, W = x.shape
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
+    if x.dtype == torch.float16:
+        # a half-precision tensor of the fp16 activation chain (conv3x3_f16): pack=2 keeps it one (same exponent), pack=False
+        # gives the fp32 map (unscaled)
+        if x_rec is None or pack not in (False, 0, 2) or (pack == 2 and y_rec is None):
+            raise RuntimeError("a half-precision input needs its range record (and a record for a half-precision output)")
+        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float16 if pack == 2 else torch.float32, device=x.device,
+                        memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_maxpool2x2_ceil_f16_nhwc(x.data_ptr(), x_rec.data_ptr(), y.data_ptr(), int(pack == 2),
+                                                   None if y_rec is None else y_rec.data_ptr(), B, H, W, C,
+                                                   torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_f16_nhwc")
+        return y
     if pack and y_rec is None:
         raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
     if pack and x_rec is None:

@@ -199,6 +199,23 @@ __global__ void conv3x3_pack_weights_f16_kernel(const float* __restrict__ w, uin
     }
 }
 
+// { max_n sum_k |w[n][k]|, max_n |bias[n]| } behind a weight plane (tail zeroed by the host wrapper): what bounds a layer's output
+// from its input's maximum — the scale of a half-precision OUTPUT tensor is fixed before any of it exists (fp16 activation chain)
+__global__ void __launch_bounds__(256) conv3x3_weight_bounds_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    uint32_t* __restrict__ tail, int Cout, int Cin) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, n = 9 * Cin;
+    float l1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) l1 += fabsf(w[(size_t)o * n + i]);
+    l1 = group_sum<64>(l1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(tail, __float_as_uint((red[0] + red[1]) + (red[2] + red[3])) & 0x7fffffffu);
+        if (bias != nullptr) atomicMax(tail + 1, __float_as_uint(bias[o]) & 0x7fffffffu);
+    }
+}
+
 // weights [Cout][Cin][3][3] fp32 (torch) -> hi/lo planes [Cout][9][Cin] bf16
 __global__ void conv3x3_pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ whi, uint16_t* __restrict__ wlo,
                                             int Cout, int Cin) {
@@ -232,7 +249,8 @@ struct ConvParams {
     int relu;
     // fused one-channel producer (window kernel, C1 variant): x is not read; its values are
     // relu(b1[c] + sum_tap w1[c][tap] * mel[pixel + tap]) computed while the window is staged
-    int x_packed, y_packed;   // split8 launches: x / y are PACKED activation tensors (dasv_common.hpp, store_x8) instead of fp32
+    int x_packed, y_packed;   // 1 (split8 launches): x / y are PACKED activation tensors (dasv_common.hpp, store_x8) instead of fp32;
+                              // 2 (fp16-operand launches): x / y are fp16 NHWC tensors holding v * 2^E, E in the range record
     const uint32_t* x_rec;    // range record of x (dasv_common.hpp): required in the split8 mode — the operand planes are scaled by it
     uint32_t* y_rec;          // range record of y or null: [0] receives max |y| (atomic maximum), [1] the exponent of a packed y
     const float* mel;      // [B,H,W]
@@ -506,6 +524,19 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             if (blockIdx.x == 0 && threadIdx.x == 0) p.y_rec[1] = (uint32_t)Ey;
         }
     }
+    if constexpr (PREC == PREC_F16) {
+        // fp16 activation chain: a half-precision x holds v * 2^Ex (Ex in its record), a half-precision y is written as v * 2^Ey
+        // with Ey from the bound on the layer's output (see above; the bounds sit behind the fp16 weight plane)
+        if (p.x_packed == 2) sxinv = x8_pow2(-(int)p.x_rec[1]);
+        if (p.y_packed == 2) {
+            const float* tail = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.whi) + (size_t)p.Cout * 9 * Cin * 2);
+            const float bound = (__uint_as_float(p.x_rec[0] & 0x7fffffffu) * tail[0] + tail[1]) * 1.001f;
+            // fp16 holds 65504: the bound goes to [2^14, 2^15) — the true maximum sits a few binades below it
+            const int Ey = x8_exp_for(__float_as_uint(bound)) + 7;
+            sy = x8_pow2(Ey > 126 ? 126 : Ey);
+            if (blockIdx.x == 0 && threadIdx.x == 0) p.y_rec[1] = (uint32_t)(Ey > 126 ? 126 : Ey);
+        }
+    }
     uint32_t amax_u = 0u;   // max of the sign-cleared bits of the values this lane stores (range record of y)
     // what the record held when this tile began: only a larger maximum is posted (dasv_common.hpp, range_note_block)
     __shared__ uint32_t s_amax;
@@ -545,6 +576,24 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         int pb = (int)pix0;
         asm volatile("" : "+v"(pb));
         const float* xc = xs - pix0 * Cin;          // = x + c0 + wach * 4
+        if constexpr (PREC == PREC_F16) {
+            if (p.x_packed == 2) {
+                // half-precision x: a pixel's 64-channel slab is 128 bytes = chunks 0-7; the staging is a copy (threads with
+                // wach >= 8 have nothing to fetch)
+                const int c0 = (int)(xc - p.x) - wach * 4;
+                const char* xb = reinterpret_cast<const char*>(p.x) + (size_t)c0 * 2 + (size_t)(wach & 7) * 16;
+#pragma unroll
+                for (int k = 0; k < WACHN; ++k) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (wach < 8 && (k < nfull || (k == nfull && wtail))) {
+                        const int pix = min(max(pb + RSTEP * k, 0), p.M - 1);
+                        v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * Cin * 2);
+                    }
+                    ra[k] = v;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};      // (defined on every path: a conditionally loaded ra[k] would stay live across the tap loops)
@@ -567,6 +616,17 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             for (int k = 0; k < WACHN; ++k)
                 if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(dst + k * (RSTEP * 128)) = ra[k];
             return;
+        }
+        if constexpr (PREC == PREC_F16) {
+            if (p.x_packed == 2) {
+                if (wach < 8) {
+                    char* dst = Ahi + lds_off(wr0, wach);
+#pragma unroll
+                    for (int k = 0; k < WACHN; ++k)
+                        if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(dst + k * (RSTEP * 128)) = ra[k];
+                }
+                return;
+            }
         }
 #pragma unroll
         for (int k = 0; k < WACHN; ++k) {
@@ -1042,10 +1102,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             const int n = n0 + wn * NPW + j * 16 + (lane >> 4) * 4;
             f32x4 sc = {1.f, 1.f, 1.f, 1.f};
             if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n) * sxinv;
+            if constexpr (PREC == PREC_F16) sc = f32x4{sxinv, sxinv, sxinv, sxinv};
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
-                if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = X8 ? acc[i][j] * sc : acc[i][j];
+                if (m < p.M) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Cout + n) = (X8 || PREC == PREC_F16) ? acc[i][j] * sc : acc[i][j];
             }
         }
         return;
@@ -1068,13 +1129,19 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + nl);
                 f32x4 sc = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n0 + nl) * sxinv;
+                constexpr bool SCALED = X8 || PREC == PREC_F16;     // (fp16 chain: sxinv undoes a half-precision input's scale)
+                if constexpr (PREC == PREC_F16) sc = f32x4{sxinv, sxinv, sxinv, sxinv};
 #pragma unroll
                 for (int i = 0; i < IB; ++i) {
-                    f32x4 v = (X8 ? acc[i][j] * sc : acc[i][j]) + bv;
+                    f32x4 v = (SCALED ? acc[i][j] * sc : acc[i][j]) + bv;
                     if (p.relu) v = relu4(v);
                     if (m0 + wm * (16 * IB) + i * 16 + (lane & 15) < p.M) note4(v);
                     char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
-                    if (p.y_packed) {
+                    if (PREC == PREC_F16 && p.y_packed == 2) {
+                        const f32x4 q = v * sy;
+                        const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
+                        *reinterpret_cast<uint2*>(row + nl * 2) = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                    } else if (p.y_packed) {
                         // PACKED output (dasv_common.hpp): the row image is the pixel's two 256-byte slabs; the small stores that
                         // made a packed epilogue cost the layer 18 % when they went to memory are LDS stores here
                         uint32_t h01, h23, v8, r8;
@@ -1096,6 +1163,20 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             __syncthreads();
             DASV_STAMP(62);
             if (p.y_rec != nullptr && tid == 0 && s_amax > rec_seen) atomicMax(p.y_rec, s_amax);
+            if (PREC == PREC_F16 && p.y_packed == 2) {
+                // half-precision rows: 256 bytes per pixel and 128-channel tile, 32 pixels per pass of the workgroup
+                const int col16 = tid & 15;
+#pragma unroll
+                for (int k = 0; k < TBM / 32; ++k) {
+                    const int pix = (tid >> 4) + 32 * k;
+                    const int m = m0 + pix;
+                    if (m < p.M)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.y) + ((size_t)m * p.Cout + n0) * 2 + col16 * 16) =
+                            *reinterpret_cast<const f32x4*>(smem + pix * OP + col16 * 16);
+                }
+                DASV_STAMP(63);
+                return;
+            }
             const int col = tid & 31;            // 16-byte chunk of a pixel's 512-byte row; 16 pixels per pass of the workgroup
 #pragma unroll
             for (int k = 0; k < TBM / 16; ++k) {
@@ -1118,12 +1199,13 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f};
         if constexpr (X8) sc = *reinterpret_cast<const f32x4*>(winv + n) * sxinv;
+        if constexpr (PREC == PREC_F16) sc = f32x4{sxinv, sxinv, sxinv, sxinv};
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const int m = m0 + wm * (16 * IB) + i * 16 + (lane & 15);
             if (m < p.M) {
-                f32x4 v = (X8 ? acc[i][j] * sc : acc[i][j]) + bv;
+                f32x4 v = ((X8 || PREC == PREC_F16) ? acc[i][j] * sc : acc[i][j]) + bv;
                 if (p.relu) v = relu4(v);
                 if (p.mask != nullptr) {
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n);
@@ -1131,7 +1213,12 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                     for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
                 }
                 note4(v);
-                if (p.y_packed) store_x8(p.y, m, p.Cout, n, v, sy);
+                if (PREC == PREC_F16 && p.y_packed == 2) {
+                    const f32x4 q = v * sy;
+                    const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)m * p.Cout + n) * 2) =
+                        make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                } else if (p.y_packed) store_x8(p.y, m, p.Cout, n, v, sy);
                 else *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
                 csum += v;
             }
@@ -1233,15 +1320,25 @@ int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16,
     return (int)hipGetLastError();
 }
 
-int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream) {
+size_t dasv_conv3x3_packed_weight_bytes_f16(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)Cout * 9 * Cin * sizeof(uint16_t) + 16;     // the fp16 plane | { L1 bound, max |bias|, 0, 0 }
+}
+
+int dasv_conv3x3_pack_weights_f16(const float* w, const float* bias, void* w_f16, int Cout, int Cin, dasv_stream_t stream) {
     if (w == nullptr || w_f16 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0) return DASV_E_SHAPE;
     const long long n = (long long)Cout * 9 * Cin;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(dasv::conv3x3_pack_weights_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                        static_cast<uint16_t*>(w_f16), Cout, Cin);
+    hipError_t e = hipMemsetAsync(static_cast<char*>(w_f16) + (size_t)n * 2, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dasv::conv3x3_weight_bounds_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       reinterpret_cast<uint32_t*>(static_cast<char*>(w_f16) + (size_t)n * 2), Cout, Cin);
     return (int)hipGetLastError();
 }
+
 
 static int conv3x3_launch(int mode, const float* x, const float* mel, const float* w1, const float* b1, const void* w_hi,
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
@@ -1263,8 +1360,11 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.part = nullptr; p.ksplit = 1;
     p.x_packed = x_packed; p.y_packed = y_packed;
     p.x_rec = x_rec; p.y_rec = y_rec;
-    if ((x_packed || y_packed) && (mode != 3 || mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
+    if ((x_packed || y_packed) && (mask != nullptr || colsum != nullptr || mel != nullptr)) return DASV_E_SHAPE;
+    if ((x_packed == 1 || y_packed == 1) && mode != 3) return DASV_E_SHAPE;        // packed split8 planes
+    if ((x_packed == 2 || y_packed == 2) && (mode != 2 || W > 80)) return DASV_E_SHAPE;   // fp16 tensors: the fp16-operand window kernel
     if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
+    if ((x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
     p.row_span = row_span;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     hipStream_t s = (hipStream_t)stream;
@@ -1378,6 +1478,14 @@ int dasv_debug_conv_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasv::dasv_conv_stamps), sizeof(unsigned long long) * 64);
 }
 #endif
+
+int dasv_conv3x3_bias_relu_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias, void* y,
+                                    int y_f16, uint32_t* y_range, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                    int Cin, int Cout, int relu, dasv_stream_t stream) {
+    return conv3x3_launch(2, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, nullptr, bias, nullptr, nullptr,
+                          static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
+                          x_f16 ? 2 : 0, y_f16 ? 2 : 0, x_range, y_range);
+}
 
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                        const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,

@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         uint32_t m = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const uint32_t o = __float_as_uint(c1_red[k]); m = o > m ? o : m; }
-        const int Ey = x8_exp_for(__float_as_uint(__uint_as_float(m) * 1.001f));
+        int Ey = x8_exp_for(__float_as_uint(__uint_as_float(m) * 1.001f));
+        if (pack == 2) Ey = Ey + 7 > 126 ? 126 : Ey + 7;      // a half-precision tensor: the bound goes to [2^14, 2^15) (fp16 holds 65504)
         sy = x8_pow2(Ey);
         if (blockIdx.x == 0 && threadIdx.x == 0) y_rec[1] = (uint32_t)Ey;
     }
@@ -104,7 +105,13 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
                 // PACKED output for a split8 consumer (dasv_common.hpp).  (Its three small stores per lane are not what the packed
                 // form costs here — a wave-local LDS transpose into 16-byte stores changed nothing, 0.221 vs 0.225 ms: with 36 FMAs and
                 // the 28-instruction conversion per lane the kernel is bound by vector issue at this write rate.)
-                if (pack) store_x8(y, pix, Cout, q * 4, o, sy);
+                if (pack == 2) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const h2 a = __builtin_convertvector(f2{o[0] * sy, o[1] * sy}, h2), b2 = __builtin_convertvector(f2{o[2] * sy, o[3] * sy}, h2);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y) + ((size_t)pix * Cout + q * 4) * 2) =
+                        make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                } else if (pack) store_x8(y, pix, Cout, q * 4, o, sy);
                 else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
             }
         }
@@ -136,13 +143,17 @@ __global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restri
 __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int H, int W, int C, int Ho, int Wo, long long nvec,
                                                               const int* __restrict__ pool_src, int pack,
-                                                              const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec) {
+                                                              const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec, int in_f16) {
+    // in_f16: x is a half-precision tensor holding v * 2^Ex (fp16 activation chain).  pack 2: y is one too, with the SAME exponent
+    // (the maximum commutes with a positive scale: the halves are compared and copied, nothing is rounded); pack 0 with in_f16:
+    // fp32 out, unscaled.
     const int cq = C >> 2;
     float sy = 1.f;
     if (x_rec != nullptr) {
         const uint32_t xa = x_rec[0];
-        const int Ey = x8_exp_for(xa);
-        sy = x8_pow2(Ey);
+        int Ey = x8_exp_for(xa);
+        if (in_f16) Ey = (int)x_rec[1];
+        sy = in_f16 ? x8_pow2(-Ey) : x8_pow2(Ey);          // fp16 in: the factor that UNDOES the input's scale (fp32 out)
         if (y_rec != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { y_rec[0] = xa; y_rec[1] = (uint32_t)Ey; }
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
@@ -154,6 +165,27 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
         const int w0 = 2 * wo;
         bool hh = h0 + 1 < H;
         if (pool_src != nullptr) { h0 = pool_src[2 * ho]; hh = pool_src[2 * ho + 1] != 0; }
+        if (in_f16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const char* hb = reinterpret_cast<const char*>(x) + ((((size_t)b * H + h0) * W + w0) * C + q * 4) * 2;
+            auto ld = [&](size_t off) { return __builtin_convertvector(*reinterpret_cast<const h4*>(hb + off * 2), f4); };
+            auto mxh = [](f4 a, f4 v) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = (v[c] > a[c] || v[c] != v[c]) ? v[c] : a[c];
+                return a;
+            };
+            f4 m = ld(0);
+            const bool hw2 = w0 + 1 < W;
+            if (hw2) m = mxh(m, ld(C));
+            if (hh) m = mxh(m, ld((size_t)W * C));
+            if (hw2 && hh) m = mxh(m, ld((size_t)W * C + C));
+            if (pack == 2) {
+                *reinterpret_cast<h4*>(reinterpret_cast<char*>(y) + ((size_t)op * C + q * 4) * 2) = __builtin_convertvector(m, h4);
+            } else {
+                *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m * sy;
+            }
+            continue;
+        }
         const float* base = x + (((size_t)b * H + h0) * W + w0) * C + q * 4;
         f4 m = *reinterpret_cast<const f4*>(base);
         const bool hw = w0 + 1 < W;
@@ -307,7 +339,7 @@ static int c1_launch(const float* x, const float* w, const float* bias, float* y
     if (x == nullptr || w == nullptr || y == nullptr) return DASV_E_NULL;
     if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;   // a packed output is scaled from the input's range
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
-    if (pack && Cout % 64 != 0) return DASV_E_SHAPE;
+    if (pack == 1 && Cout % 64 != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
     if (W > 4000) return DASV_E_SHAPE;                                   // the chunk's input run (512 + 2 W + 2 floats) lives in LDS
     long long blocks = (npix + 511) / 512;                               // 512-pixel chunks (C1_CHUNK)
@@ -352,17 +384,30 @@ int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const uint32_t* x_r
 }
 
 static int pool_launch(const float* x, float* y, const int* pool_src, int B, int H, int Ho, int W, int C, int pack,
-                       const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream) {
+                       const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream, int in_f16 = 0) {
     if (x == nullptr || y == nullptr) return DASV_E_NULL;
     if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;
-    if (B <= 0 || H <= 0 || Ho <= 0 || W <= 0 || C <= 0 || C % (pack ? 64 : 4) != 0) return DASV_E_SHAPE;
+    if (in_f16 && (x_range == nullptr || pack == 1)) return in_f16 && x_range == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
+    if (pack == 2 && !in_f16) return DASV_E_SHAPE;
+    if (B <= 0 || H <= 0 || Ho <= 0 || W <= 0 || C <= 0 || C % (pack == 1 ? 64 : 4) != 0) return DASV_E_SHAPE;
     const int Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo,
-                       nvec, pool_src, pack, x_range, y_range);
+                       nvec, pool_src, pack, x_range, y_range, in_f16);
     return (int)hipGetLastError();
+}
+
+int dasv_maxpool2x2_ceil_f16_nhwc(const void* x_f16, const uint32_t* x_range, void* y, int y_f16, uint32_t* y_range, int B, int H,
+                                  int W, int C, dasv_stream_t stream) {
+    return pool_launch(static_cast<const float*>(x_f16), static_cast<float*>(y), nullptr, B, H, (H + 1) / 2, W, C, y_f16 ? 2 : 0,
+                       x_range, y_range, stream, 1);
+}
+
+int dasv_conv3x3_c1_bias_relu_f16_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_f16,
+                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, static_cast<float*>(y_f16), B, H, W, Cout, relu, nullptr, stream, 2, x_range, y_range);
 }
 
 int dasv_maxpool2x2_ceil_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, int B, int H, int W, int C,

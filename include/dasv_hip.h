@@ -147,7 +147,10 @@ int dasv_dmha_bwd(int x_dtype, const void* x, const float* query, const float* a
  * ------------------------------------------------------------------------ */
 size_t dasv_conv3x3_packed_weight_bytes(int Cout, int Cin);
 int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, dasv_stream_t stream);
-int dasv_conv3x3_pack_weights_f16(const float* w, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
+/* (bias: the layer's bias or NULL — behind the fp16 plane sit { max_n sum_k |w[n][k]|, max |bias| }, the bound on the layer's
+ * output that scales a half-precision output tensor; w_f16 holds dasv_conv3x3_packed_weight_bytes_f16(Cout, Cin) bytes) */
+size_t dasv_conv3x3_packed_weight_bytes_f16(int Cout, int Cin);
+int dasv_conv3x3_pack_weights_f16(const float* w, const float* bias, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
 /*       mode 3 ("split8"): fp32-grade on fewer matrix-pipe cycles, FORWARD / activations only, maps up to 80 columns: the
  *               operand c = v * 2^E is split c = hi + r with hi = fp16(c); hi*hi on the fp16 MFMA, both cross terms hi*r' + r*hi'
  *               on one block-scaled e4m3 MFMA per 64 input channels (residuals are 2^-11 of the value, 4 significant bits
@@ -290,6 +293,25 @@ int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, c
                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,
                                  int C, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Half-precision activation chain (mode 2, fp16 operands: BASELINE config 3 "bf16" / config 5 "fp16 MFMA path" name 16-bit
+ * arithmetic).  Between the layers of an inference front-end the activations are stored as fp16 NHWC tensors (2 bytes per
+ * element: half the HBM traffic of every layer, and the convolution's window staging becomes a copy) holding v * 2^E with E in
+ * the tensor's range record — the same device-side scaling as the packed split8 tensors, so fp16's range (65504) is never the
+ * limit: E comes from the bound on the layer's output, mapped to [2^14, 2^15).  x_f16 / y_f16: 0 = fp32 tensor, 1 = fp16 tensor.
+ *   dasv_conv3x3_bias_relu_f16_nhwc   x_range required when x_f16 or y_f16, y_range when y_f16 (optional otherwise)
+ *   dasv_conv3x3_c1_bias_relu_f16_nhwc  conv11 -> fp16 tensor (x_range: the record of the input features)
+ *   dasv_maxpool2x2_ceil_f16_nhwc     fp16 tensor in; fp16 out (same exponent: halves are compared and copied) or fp32 out (unscaled)
+ * Replaces nothing new in the reference: CNNs.py:72-86 in eval mode with 16-bit storage.
+ * ------------------------------------------------------------------------ */
+int dasv_conv3x3_bias_relu_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias, void* y,
+                                    int y_f16, uint32_t* y_range, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                    int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_f16_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_f16,
+                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_f16_nhwc(const void* x_f16, const uint32_t* x_range, void* y, int y_f16, uint32_t* y_range, int B, int H,
+                                  int W, int C, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * The same two launches on the front-end's own NHWC map: x / grad_x are [B, T, F, C] fp32 (what a channels_last

@@ -284,3 +284,43 @@ def test_narrow_kernel_size_training_gradients_match_pytorch():
         # direction and size, not each element: on these small maps one ReLU sign / pool arg-max decided the other way by the
         # ~1e-5 forward difference moves a channel's gradient by percents (tools/_diag/narrow_grad.py: single layers agree to 6e-6)
         assert cosv > 0.9995 and float((a - b).abs().max()) <= 5e-2 * float(b.abs().max()), (k, cosv)
+
+
+def test_fp16_activation_chain_vs_oracle_and_range():
+    """BASELINE config 3 names bf16 and config 5 the "fp16 MFMA path": with conv_mode "fp16" the inference front-end stores its
+    activations as fp16 tensors between the layers (2 bytes per element, scaled per tensor by range records: conv.conv3x3_f16).
+    Default model at B=16, T=300 against oracle.embedding_forward (stated bar for 16-bit arithmetic: 1e-3 relative — the same as
+    the fp32 bar — and cosine within 1e-4), against the same mode with fp32 storage, and with activations far beyond fp16's
+    65504 (weights rescaled), where unscaled fp16 storage would saturate."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
+    net.front_end.conv_mode = "fp16"
+    x = torch.from_numpy(rnd(41, 16, 300, 80))
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        assert net.front_end.half_activations and net.front_end._packed_chain_ok(80, 16, 300)
+        emb = net.getEmbedding(x.to(DEV)).cpu()
+        net.front_end.half_activations = False
+        emb32 = net.getEmbedding(x.to(DEV)).cpu()
+        net.front_end.half_activations = True
+        ref = oracle.embedding_forward(x, sd, 4, 32)
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("fp16 operands + fp16 activation storage: embedding rel err %.2e (fp32 storage: %.2e), min cosine %.8f"
+          % (_rel(emb, ref), _rel(emb32, ref), cos))
+    assert _rel(emb, ref) < 1e-3 and 1 - cos < 1e-4
+    with torch.no_grad():
+        for name, f in (("conv12", 300.0), ("conv22", 300.0), ("conv32", 100.0)):
+            getattr(net.front_end, name).weight.mul_(f)
+            getattr(net.front_end, name).bias.mul_(f)
+        net.fc1.weight.mul_(1e-6)
+        fmap = net.front_end.forward_map(x.to(DEV))
+        big = float(fmap.abs().max())
+        emb = net.getEmbedding(x.to(DEV)).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = oracle.embedding_forward(x, sd, 4, 32)
+    print("front-end map maximum %.4g (fp16 holds 65504): embedding rel err %.2e" % (big, _rel(emb, ref)))
+    assert big > 65504 and bool(torch.isfinite(fmap).all())
+    assert _rel(emb, ref) < 1e-3

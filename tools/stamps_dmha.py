@@ -19,7 +19,7 @@ SO = os.path.join(DIAG, "libdasv_diag.so")
 def build():
     os.makedirs(DIAG, exist_ok=True)
     src = os.path.join(ROOT, "doubleattentionspeakerverification_amd", "csrc", "dmha_fwd.hip")
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DDASV_STAMPS",
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DDASV_STAMPS", "-DDASV_DEBUG",
                            "-o", SO, src])
     print("built", SO)
 
