@@ -66,6 +66,12 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
     __shared__ uint32_t s_amax;
     if (threadIdx.x == 0) s_amax = 0u;      // visible behind the barriers of the chunk loop (every block runs at least one chunk)
     const int halo = W + 1, span = C1_CHUNK + 2 * halo;
+    // Per chunk: the raw input run goes to LDS, then ONE thread per pixel gathers the pixel's nine taps — border tests, the two
+    // integer divisions that locate the pixel in its image, zeros outside — into a row of nine floats; the Cout/4 lanes of a pixel
+    // then read that row (a broadcast) and do nothing but 36 FMAs.  (Round 2 / early round 3 had every lane of every pixel redo
+    // the divisions and the nine border selects: ~100 of its ~140 vector instructions per output quad, and the kernel sat at
+    // 167-185 us for 786 / 393 MB whatever the output format.)
+    float* c1_cols = c1_in + ((span + 3) & ~3);      // [C1_CHUNK][9]
     for (long long p0 = (long long)blockIdx.x * C1_CHUNK; p0 < npix; p0 += (long long)gridDim.x * C1_CHUNK) {
         __syncthreads();                             // the previous chunk's readers are done
         for (int i = threadIdx.x; i < span; i += blockDim.x) {
@@ -73,24 +79,30 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
             c1_in[i] = (g >= 0 && g < npix) ? x[g] : 0.f;
         }
         __syncthreads();
+        const int nloc = (int)((npix - p0) < C1_CHUNK ? (npix - p0) : C1_CHUNK);
+        for (int l = threadIdx.x; l < nloc; l += blockDim.x) {
+            const long long pix = p0 + l;
+            const int w_ = (int)(pix % W);
+            int h_ = (int)((pix / W) % H), hend = H;
+            if (row_span != nullptr) {   // ragged batch: image borders from the row table
+                const int r = (int)(pix / W), lo = row_span[2 * r];
+                h_ = r - lo;
+                hend = row_span[2 * r + 1] - lo;
+            }
+            const float* ctr = c1_in + l + halo;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                c1_cols[l * 9 + t] = ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) ? ctr[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+            }
+        }
+        __syncthreads();
         if (pl < ppb) {
-            const int nloc = (int)((npix - p0) < C1_CHUNK ? (npix - p0) : C1_CHUNK);
             for (int l = pl; l < nloc; l += ppb) {
                 const long long pix = p0 + l;
-                const int w_ = (int)(pix % W);
-                int h_ = (int)((pix / W) % H), hend = H;
-                if (row_span != nullptr) {   // ragged batch: image borders from the row table
-                    const int r = (int)(pix / W), lo = row_span[2 * r];
-                    h_ = r - lo;
-                    hend = row_span[2 * r + 1] - lo;
-                }
-                const float* ctr = c1_in + l + halo;
                 float in[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-                    in[t] = ((unsigned)hh < (unsigned)hend && (unsigned)ww < (unsigned)W) ? ctr[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
-                }
+                for (int t = 0; t < 9; ++t) in[t] = c1_cols[l * 9 + t];
                 f4 o = bv;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -102,9 +114,7 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) amax_u = max(amax_u, __float_as_uint(o[c]) & 0x7fffffffu);
-                // PACKED output for a split8 consumer (dasv_common.hpp).  (Its three small stores per lane are not what the packed
-                // form costs here — a wave-local LDS transpose into 16-byte stores changed nothing, 0.221 vs 0.225 ms: with 36 FMAs and
-                // the 28-instruction conversion per lane the kernel is bound by vector issue at this write rate.)
+                // PACKED output for a split8 consumer (dasv_common.hpp) / half-precision output for the fp16 chain
                 if (pack == 2) {
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -344,7 +354,7 @@ static int c1_launch(const float* x, const float* w, const float* bias, float* y
     if (W > 4000) return DASV_E_SHAPE;                                   // the chunk's input run (512 + 2 W + 2 floats) lives in LDS
     long long blocks = (npix + 511) / 512;                               // 512-pixel chunks (C1_CHUNK)
     if (blocks > 256 * 16) blocks = 256 * 16;
-    const size_t lds = (size_t)(512 + 2 * W + 2) * sizeof(float);
+    const size_t lds = (size_t)(((512 + 2 * W + 2 + 3) & ~3) + 512 * 9) * sizeof(float);   // the input run | [512][9] gathered taps
     hipLaunchKernelGGL(dasv::conv3x3_c1_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, w, bias, y, H, W,
                        Cout, npix, relu, row_span, pack, x_range, y_range);
     return (int)hipGetLastError();
