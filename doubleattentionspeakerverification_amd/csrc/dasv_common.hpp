@@ -95,6 +95,29 @@ template <int G> __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Reductions over the whole wave WITHOUT the LDS crossbar (ds_bpermute, ~100+ cycles of latency per step): inside a row of 16
+// lanes by DPP permutations, across the four rows by row_bcast:15 / row_bcast:31 (GFX9 DPP controls: lane 15 of a row to the next
+// row, lane 31 to rows 2 and 3), the result read from lane 63 into a scalar register — every lane gets it.  `ROW_UNIFORM_G`: the
+// value is already uniform over aligned groups of that many lanes (1 = arbitrary per-lane values).
+template <int ROW_UNIFORM_G> __device__ __forceinline__ float wave_sum_all(float v) {
+    if constexpr (ROW_UNIFORM_G < 2) v += dpp_mov<0xB1>(v);
+    if constexpr (ROW_UNIFORM_G < 4) v += dpp_mov<0x4E>(v);
+    if constexpr (ROW_UNIFORM_G < 8) v += dpp_mov<0x141>(v);
+    if constexpr (ROW_UNIFORM_G < 16) v += dpp_mov<0x140>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // rows 1, 3 += rows 0, 2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // rows 2, 3 += row 1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int ROW_UNIFORM_G> __device__ __forceinline__ float wave_max_all(float v) {
+    if constexpr (ROW_UNIFORM_G < 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if constexpr (ROW_UNIFORM_G < 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if constexpr (ROW_UNIFORM_G < 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if constexpr (ROW_UNIFORM_G < 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xF, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 
 // write-through (agent-scope) accesses for data exchanged between workgroups inside one launch

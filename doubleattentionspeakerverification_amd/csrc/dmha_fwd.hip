@@ -56,6 +56,7 @@ struct FwdParams {
     int wpu;               // waves cooperating on one unit
     int upw;               // units per workgroup
     int arrivals;          // workgroups per utterance = H / upw
+    int nparts;            // partials per utterance the head stage merges: `arrivals` (folded per workgroup) or H (one per head)
     int t_pad;             // score row pitch (floats)
     float* s_glob;         // generic kernel, T too long for LDS: [B*H][t_pad] raw scores in the workspace (else null)
     float qscale;          // log2(e) / sqrt(H)
@@ -127,7 +128,7 @@ __device__ __forceinline__ void fold_publish(const FwdParams& p, int b, int a, c
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float S = 0.f;
     for (int k = 0; k < upw; ++k) S += fast_exp2((ubuf[k] - Mu) * kLog2e);
-    float* pp = p.exch_p + ((size_t)b * p.arrivals + a) * pitch;
+    float* pp = p.exch_p + ((size_t)b * p.nparts + a) * pitch;
     if (lane < upw) store_agent(p.exch_u + (size_t)b * round_up_i(p.H, 4) + a * upw + lane, ubuf[lane]);
     if constexpr (VEC4) {
         if (lane == 0) store_agent4(pp, 0, pitch * 4, hs_f4{M, S, 0.f, 0.f});
@@ -153,7 +154,7 @@ __device__ __forceinline__ void fold_publish(const FwdParams& p, int b, int a, c
 template <bool VEC4>
 __device__ __forceinline__ void head_stage(const FwdParams& p, int b, float* lds) {
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-    const int H = p.H, dh = p.dh, A = p.arrivals, hpad = round_up_i(H, 4), pitch = part_pitch(dh);
+    const int H = p.H, dh = p.dh, A = p.nparts, hpad = round_up_i(H, 4), pitch = part_pitch(dh);
     float* fw = lds;                 // [A <= H] e^(M_a - M)
     float* stat = lds + hpad;        // {1/S}
     const float* pg = p.exch_p + (size_t)b * A * pitch;
@@ -397,14 +398,12 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     // (4) wave-level (max, sum) by xor butterflies over the groups (2 values only); every group rescales its
     //     accumulator to the wave's max and parks it in its own LDS slot
     {
-        float mw = m;
-#pragma unroll
-        for (int off = G; off < 64; off <<= 1) mw = fmaxf(mw, __shfl_xor(mw, off));
+        // (m, l) are uniform over each group of G lanes: the wave's maximum and the sum over its groups by DPP (each group
+        // counted once), not through the LDS crossbar (four dependent ds_bpermute round trips in round 2)
+        const float mw = wave_max_all<G>(m);
         const float mwu = (mw == -INFINITY) ? 0.f : mw;
         const float sc = fast_exp2(m - mwu);
-        float lw = l * sc;
-#pragma unroll
-        for (int off = G; off < 64; off <<= 1) lw += __shfl_xor(lw, off);
+        const float lw = wave_sum_all<G>(l * sc);
         if (lane == 0) { red_ml[2 * w] = mw; red_ml[2 * w + 1] = lw; }
         float* ra = red_acc + (size_t)(uu * P + phase) * DH;
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -443,6 +442,7 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
     const float invL = (L > 0.f) ? 1.0f / L : 0.f;
     float* cbuf = red_acc + (size_t)upw * P * DH;            // [upw][DH] the workgroup's context vectors
     float* ubuf = cbuf + (size_t)upw * DH;                   // [upw] their (masked) head scores
+    const bool direct = p.nparts == H && p.arrivals != H;    // per-head partials published by the units' first waves themselves
     if (wu == 0) {
         float* cg = p.ctx != nullptr ? p.ctx + ((size_t)b * H + h) * DH : nullptr;
         const float* ua = red_acc + (size_t)uu * P * DH;
@@ -463,13 +463,25 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
                 }
                 const float cv = v * invL;
                 if (cg != nullptr) cg[d] = cv;               // a plain output: nothing in this launch reads it back
-                cbuf[(size_t)uu * DH + d] = cv;
+                if (direct) store_agent(p.exch_p + ((size_t)b * H + h) * part_pitch(DH) + 4 + d, cv);   // V of this head's own partial
+                else cbuf[(size_t)uu * DH + d] = cv;
                 upart = fmaf(cv, attv[kd], upart);
             }
         }
         if (p.att != nullptr) {
-            upart = group_sum<64>(upart);
-            if (lane == 0) ubuf[uu] = (p.keep != nullptr && p.keep[(size_t)b * H + h] == 0) ? -INFINITY : upart;
+            upart = wave_sum_all<1>(upart);
+            const float um = (p.keep != nullptr && p.keep[(size_t)b * H + h] == 0) ? -INFINITY : upart;
+            if (direct) {
+                // one partial per HEAD {M = u_h, S = [not masked], V = c_h}: no fold over the workgroup's heads, no second barrier —
+                // for small exchanges (BASELINE config 2: 8 x 68 floats per utterance) the fold's barrier + publish cost more than
+                // the last arriver saves by pulling fewer partials
+                if (lane == 0) {
+                    float* pp = p.exch_p + ((size_t)b * H + h) * part_pitch(DH);
+                    store_agent(pp, um);
+                    store_agent(pp + 1, um == -INFINITY ? 0.f : 1.f);
+                    store_agent(p.exch_u + (size_t)b * round_up_i(H, 4) + h, um);
+                }
+            } else if (lane == 0) ubuf[uu] = um;
         }
         if (p.ml != nullptr && lane == 0) {
             p.ml[((size_t)b * H + h) * 2] = M;
@@ -485,6 +497,25 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         }
     };
     if (p.att == nullptr) { write_align(); return; }
+    if (direct) {
+        // every publishing wave drains its write-through stores, the workgroup joins, ONE lane takes the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        DASV_STAMP(p, 4);
+        int ticket = 0;
+        if (tid == 0) ticket = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        write_align();
+        if (tid == 0) {
+            const int last = (ticket == p.arrivals - 1);
+            if (last) __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        DASV_STAMP(p, 5);
+        if (*flag != 0) head_stage<true>(p, b, smem);
+        DASV_STAMP(p, 6);
+        return;
+    }
     __syncthreads();                                         // cbuf / ubuf of every unit are in LDS
     publish_and_finish<true>(p, b, a, cbuf, ubuf, smem, flag, write_align);
     DASV_STAMP(p, 6);
@@ -762,6 +793,9 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
         }
         nw = upw * wpu;
         p.wpu = wpu; p.upw = upw; p.arrivals = H / upw;
+        // small exchanges: one partial per head, published by the units themselves (no fold); large ones (the model's 32 x 160
+        // pooling): one folded partial per workgroup
+        p.nparts = (upw > 1 && (size_t)H * part_pitch(dh) * sizeof(float) <= 4096) ? H : p.arrivals;
         const size_t lds = fwd_lds_floats(upw, p.t_pad, wpu, wpu * gpw, H, dh) * sizeof(float) + (size_t)g_tuning.lds_pad;
         if (lds <= 160 * 1024) {
             dim3 grid((unsigned)(groups8 * p.arrivals)), block((unsigned)(nw * 64));
@@ -783,7 +817,7 @@ static int fwd_impl(const void* x, const float* query, const float* att, const u
     }
     if (perm_f > 0) return DASV_E_SHAPE;   // no shape-agnostic form of the NHWC addressing: the caller permutes instead
     // shape-agnostic path
-    p.wpu = 4; p.upw = 1; p.arrivals = H;
+    p.wpu = 4; p.upw = 1; p.arrivals = H; p.nparts = H;
     const bool in_lds = generic_scores_fit_lds(T, H, dh);
     if (!in_lds) {
         if (workspace == nullptr || workspace_bytes < dasv_dmha_workspace_bytes(B, T, H, dh)) return DASV_E_WORKSPACE;
