@@ -145,6 +145,19 @@ class ConvTimer:
                 self.rec.append((s, e, 2.0 * 9 * cin * conv.out_channels * rows * W))
                 return y
             ragmod._conv_ragged = timedr
+            innerr16 = ragmod._conv_ragged_f16
+
+            def timedr16(x, conv, *a, **k):
+                if not self.active:
+                    return innerr16(x, conv, *a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(torch.cuda.current_stream(x.device))
+                y = innerr16(x, conv, *a, **k)
+                e.record(torch.cuda.current_stream(x.device))
+                rows, W, cin = x.shape
+                self.rec.append((s, e, 2.0 * 9 * cin * conv.out_channels * rows * W))
+                return y
+            ragmod._conv_ragged_f16 = timedr16
 
     def summary(self):
         if not self.rec:

@@ -41,6 +41,10 @@ SIGNATURES = {
                                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_f16_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_f16_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_ragged_f16_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                       c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_ragged_f16_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_bias_relu_nhwc_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1487,6 +1487,15 @@ int dasv_conv3x3_bias_relu_f16_nhwc(const void* x, int x_f16, const uint32_t* x_
                           x_f16 ? 2 : 0, y_f16 ? 2 : 0, x_range, y_range);
 }
 
+int dasv_conv3x3_bias_relu_ragged_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
+                                           void* y, int y_f16, uint32_t* y_range, const int* row_span, void* workspace,
+                                           size_t workspace_bytes, int rows, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return conv3x3_launch(2, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, nullptr, bias, nullptr, nullptr,
+                          static_cast<float*>(y), workspace, workspace_bytes, 1, rows, W, Cin, Cout, relu, stream, row_span,
+                          x_f16 ? 2 : 0, y_f16 ? 2 : 0, x_range, y_range);
+}
+
 int dasv_conv3x3_bias_relu_ragged_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* bias, float* y,
                                        const int* row_span, void* workspace, size_t workspace_bytes, int rows, int W, int Cin,
                                        int Cout, int relu, dasv_stream_t stream) {

@@ -420,6 +420,20 @@ int dasv_conv3x3_c1_bias_relu_f16_nhwc(const float* x, const uint32_t* x_range, 
     return c1_launch(x, w, bias, static_cast<float*>(y_f16), B, H, W, Cout, relu, nullptr, stream, 2, x_range, y_range);
 }
 
+int dasv_maxpool2x2_ceil_ragged_f16_nhwc(const void* x_f16, const uint32_t* x_range, void* y, int y_f16, uint32_t* y_range,
+                                         const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (pool_src == nullptr) return DASV_E_NULL;
+    return pool_launch(static_cast<const float*>(x_f16), static_cast<float*>(y), pool_src, 1, rows_in, rows_out, W, C, y_f16 ? 2 : 0,
+                       x_range, y_range, stream, 1);
+}
+
+int dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_f16,
+                                              uint32_t* y_range, const int* row_span, int rows, int W, int Cout, int relu,
+                                              dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return c1_launch(x, w, bias, static_cast<float*>(y_f16), 1, rows, W, Cout, relu, row_span, stream, 2, x_range, y_range);
+}
+
 int dasv_maxpool2x2_ceil_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, int B, int H, int W, int C,
                               dasv_stream_t stream) {
     return pool_launch(x, y, nullptr, B, H, (H + 1) / 2, W, C, 0, x_range, y_range, stream);

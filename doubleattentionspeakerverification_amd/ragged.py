@@ -118,6 +118,64 @@ def _packed_chain_ok(front, rows, W, pools):
     return True
 
 
+def _conv_ragged_f16(x, conv, w_f16, span, x_rec, y_rec):
+    """One ragged convolution of the half-precision chain: [rows, W, Cin] fp16 -> [rows, W, Cout] fp16 (scales in the records)."""
+    lib = _lib.load()
+    rows, W, cin = x.shape
+    y = torch.empty((rows, W, conv.out_channels), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_bias_relu_ragged_f16_nhwc(
+            x.data_ptr(), 1, x_rec.data_ptr(), w_f16.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
+            y.data_ptr(), 1, y_rec.data_ptr(), span.data_ptr(), None, 0, rows, W, cin, conv.out_channels, 1,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_f16_nhwc")
+    return y
+
+
+def _front_end_ragged_f16(front, x, spans, pools, lens, dev):
+    """front_end_ragged in the fp16-operand mode with fp16 activation storage: conv11 -> f16 -> convX1 -> f16 -> convX2 -> f16 ->
+    pool -> f16 ... -> last pool -> fp32.  Every half-precision tensor holds v * 2^E, E in its range record."""
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    W = x.shape[1]
+    recs = iter(_conv.new_ranges(dev, 2 + 3 * front.n_blocks))
+    rx, rh = next(recs), next(recs)
+    c11 = front.conv11
+    rows = x.shape[0]
+    h = torch.empty((rows, W, c11.out_channels), dtype=torch.float16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), stream), "dasv_range_absmax_f32")
+        _lib.check(lib.dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc(
+            x.data_ptr(), rx.data_ptr(), c11.weight.detach().contiguous().data_ptr(),
+            None if c11.bias is None else c11.bias.detach().data_ptr(), h.data_ptr(), rh.data_ptr(), spans[0].data_ptr(), rows, W,
+            c11.out_channels, 1, stream), "dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc")
+    for blk in range(1, front.n_blocks + 1):
+        span = spans[blk - 1]
+        for name in ("conv%d1" % blk, "conv%d2" % blk):
+            conv = getattr(front, name)
+            if conv.in_channels == 1:
+                continue
+            key = (name, dev.index)
+            packed = front._packed.get(key)
+            if packed is None:
+                packed = front._packed[key] = _conv.PackedConvWeights()
+            hi, _ = packed.get(conv.weight, "fp16", conv.bias)
+            ry = next(recs)
+            h, rh = _conv_ragged_f16(h, conv, hi, span, rh, ry), ry
+        rows_in, rows_out = h.shape[0], pools[blk - 1].shape[0]
+        Wo = (W + 1) // 2
+        last = blk == front.n_blocks
+        y = torch.empty((rows_out, Wo, h.shape[2]), dtype=torch.float32 if last else torch.float16, device=dev)
+        ry = next(recs)
+        with torch.cuda.device(dev):
+            rc = lib.dasv_maxpool2x2_ceil_ragged_f16_nhwc(h.data_ptr(), rh.data_ptr(), y.data_ptr(), 0 if last else 1, ry.data_ptr(),
+                                                          pools[blk - 1].data_ptr(), rows_in, rows_out, W, h.shape[2], stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_ragged_f16_nhwc")
+        h, W, rh = y, Wo, ry
+    frames = h.permute(0, 2, 1).reshape(h.shape[0], h.shape[2] * h.shape[1])
+    return frames, list(lens[-1])
+
+
 @torch.no_grad()
 def front_end_ragged(front, utterances, mode=None):
     """VGG front-end over stacked utterances.  Returns (frames [sum T'_i, D] with the reference's feature order c*F'+f,
@@ -136,6 +194,10 @@ def front_end_ragged(front, utterances, mode=None):
     # split8: the activations between the layers in the consumer's operand form, as in CNNs._forward_map_packed — when no launch
     # of the chain wants split-K (groups of utterances that fill the chip; a packed output has no split-K form)
     chain = mode == "split8" and getattr(front, "packed_activations", False) and _packed_chain_ok(front, x.shape[0], W, pools)
+    if mode == "fp16" and getattr(front, "half_activations", False) and _packed_chain_ok(front, x.shape[0], W, pools):
+        # the fp16-operand mode with HALF-PRECISION activation tensors between the layers (CNNs._forward_map_f16; BASELINE
+        # config 5 names exactly this: variable-length batches on the fp16 MFMA path)
+        return _front_end_ragged_f16(front, x, spans, pools, lens, dev)
     h, h_packed = None, False
     # split8: one range record per tensor of the pass (conv.new_ranges; CNNs._forward_map_packed)
     x8 = mode == "split8"

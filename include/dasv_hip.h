@@ -312,6 +312,15 @@ int dasv_conv3x3_c1_bias_relu_f16_nhwc(const float* x, const uint32_t* x_range, 
                                        uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_f16_nhwc(const void* x_f16, const uint32_t* x_range, void* y, int y_f16, uint32_t* y_range, int B, int H,
                                   int W, int C, dasv_stream_t stream);
+/* the same three over ragged batches (row_span / pool_src as above): BASELINE config 5 is "variable-length batches ... fp16 MFMA path" */
+int dasv_conv3x3_bias_relu_ragged_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
+                                           void* y, int y_f16, uint32_t* y_range, const int* row_span, void* workspace,
+                                           size_t workspace_bytes, int rows, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_f16,
+                                              uint32_t* y_range, const int* row_span, int rows, int W, int Cout, int relu,
+                                              dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_ragged_f16_nhwc(const void* x_f16, const uint32_t* x_range, void* y, int y_f16, uint32_t* y_range,
+                                         const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * The same two launches on the front-end's own NHWC map: x / grad_x are [B, T, F, C] fp32 (what a channels_last

@@ -97,6 +97,10 @@ def test_split_k_plan_and_the_packed_chain_gate(lib_path):
     assert lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(None, 1, None, None, None, None, None, 0, None, None, None, 0, 100, 40, 128, 256, 1, None) < 0
     assert lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(None, None, None, None, None, None, None, 100, 80, 128, 1, None) < 0
     assert lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc(None, None, None, None, None, 100, 50, 80, 128, None) < 0
+    # the half-precision ragged chain: tables and records are mandatory
+    assert lib.dasv_conv3x3_bias_relu_ragged_f16_nhwc(16, 1, 16, 16, None, 16, 1, 16, None, None, 0, 100, 40, 128, 256, 1, None) == -1
+    assert lib.dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc(16, 16, 16, None, 16, 16, None, 100, 80, 128, 1, None) == -1
+    assert lib.dasv_maxpool2x2_ceil_ragged_f16_nhwc(16, 16, 16, 1, 16, None, 100, 50, 80, 128, None) == -1
     # the split8 mode scales its operands by range records: without one it refuses (no silent unscaled path), also through the
     # generic entry points, which carry none
     assert lib.dasv_conv3x3_bias_relu_x8_nhwc(16, 0, None, 16, 16, None, 16, 0, None, None, 0, 1, 8, 8, 64, 128, 1, None) == -1

@@ -324,3 +324,44 @@ def test_fp16_activation_chain_vs_oracle_and_range():
     print("front-end map maximum %.4g (fp16 holds 65504): embedding rel err %.2e" % (big, _rel(emb, ref)))
     assert big > 65504 and bool(torch.isfinite(fmap).all())
     assert _rel(emb, ref) < 1e-3
+
+
+def test_ragged_fp16_activation_chain_vs_oracle():
+    """BASELINE config 5 ("variable-length batches ... fp16 MFMA path"): a ragged group in conv_mode "fp16" keeps fp16 activation
+    tensors between its layers (ragged._front_end_ragged_f16, the ragged `_f16` entry points).  Frame vectors against the same mode
+    with fp32 storage, and embeddings of a few utterances against oracle.embedding_forward at their own length (16-bit bar: 1e-3
+    relative, cosine within 1e-4)."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd import ragged
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
+    fe = net.front_end
+    fe.conv_mode = "fp16"
+    g = np.random.RandomState(78)
+    lens = [int(n) for n in g.randint(150, 801, size=40)] + [151, 17]
+    utts = [torch.from_numpy(rnd(500 + i, n, 80)) for i, n in enumerate(lens)]
+    on_dev = [u.to(DEV) for u in utts]
+    spans, pools, _ = ragged.ragged_tables(lens, fe.n_blocks, torch.device(DEV))
+    assert fe.half_activations and ragged._packed_chain_ok(fe, sum(lens), 80, pools)
+    called = []
+    orig = ragged._front_end_ragged_f16
+    try:
+        ragged._front_end_ragged_f16 = lambda *a: called.append(1) or orig(*a)
+        a, ta = ragged.front_end_ragged(fe, on_dev)
+        emb = ragged.embed_ragged(net, on_dev).cpu()
+    finally:
+        ragged._front_end_ragged_f16 = orig
+    assert len(called) == 2
+    fe.half_activations = False
+    b, tb = ragged.front_end_ragged(fe, on_dev)
+    fe.half_activations = True
+    assert ta == tb and bool(torch.isfinite(a).all())
+    d = float((a - b).abs().max() / b.abs().max())
+    print("ragged fp16 storage vs fp32 storage (fp16 operands both): frame vectors max rel diff %.2e" % d)
+    assert d < 5e-3
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    for i in (0, 13, 40, 41):
+        ref = oracle.embedding_forward(utts[i].unsqueeze(0), sd, 4, 32)[0]
+        cos = float(torch.nn.functional.cosine_similarity(emb[i], ref, dim=0))
+        assert _rel(emb[i], ref) < 1e-3 and 1 - cos < 1e-4, (lens[i], _rel(emb[i], ref), cos)
