@@ -50,8 +50,10 @@ constexpr int CBM = 128, CBN = 128, CBK = 64;
 #define DASV_CONV_STAMPS 0
 #endif
 #if DASV_CONV_STAMPS
-__device__ unsigned long long dasv_conv_stamps[64];
-#define DASV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) dasv_conv_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long dasv_conv_stamps[128];
+// slots 0-63: the 100 MHz clock; 64-127: the shader-cycle counter at the same points (their ratio is the clock the CU held)
+#define DASV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) { dasv_conv_stamps[k] = __builtin_amdgcn_s_memrealtime(); \
+                                                                                  dasv_conv_stamps[64 + (k)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define DASV_STAMP(k) do { } while (0)
 #endif
@@ -722,6 +724,28 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // the XOR swizzle moves to the SOURCE: lane L lands at (row L >> 3, slot L & 7) and fetches logical chunk (L & 7) ^ (L >> 3).
     // Wave w moves pieces 2w, 2w+1 of both planes (rows 16w ... 16w+15).  The DMA is counted in vmcnt: the __syncthreads() in
     // front of the barrier after which the tile is read drains it.
+    // Every wave waits for its OWN pieces in front of the barrier behind which the tile is read: `s_waitcnt vmcnt(0)` (gfx9 encoding:
+    // vmcnt 0, expcnt 7, lgkmcnt 15).  The compiler places the same wait for the barrier's fence while the DMA sits in straight-line
+    // code, but not once it is under a wave-uniform branch (seen in a round-3 experiment) — the protocol must not depend on that.
+    auto dma_drain = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };
+#ifndef DASV_DMA_ASM
+#define DASV_DMA_ASM 0
+#endif
+    // One 1-KB piece: lane L's 16 bytes at `src` land at `dst` + 16 L.  DASV_DMA_ASM=1 issues it as inline assembly (M0 = LDS base),
+    // which the compiler does not book as a FLAT access with an LDS side: while one of ITS OWN LDS-DMAs is pending, every lgkmcnt
+    // wait it places is a full lgkmcnt(0), so with a tile always in flight the tap loops drain their fragment reads completely in
+    // front of every MFMA group; with the assembly form the waits become counted (lgkmcnt(9), (12), ...).  Measured, same box: the
+    // counted waits are SLOWER — fp16 mode +3.9 % (tools/_diag/f16_lib_ab.py), split8 +1.1 % (tools/conv_ab_r3.py); the builtin stays.
+    auto dma_piece = [&](const void* src, char* dst) {
+#if DASV_DMA_ASM
+        const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(l), "v"(src) : "memory");
+#else
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+#endif
+    };
     auto dma_b = [&](char* Bdst, int tap, int c0) {
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -737,16 +761,20 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             for (int k = 0; k < 2; ++k) {
                 const int piece = wu * 2 + k;
                 const unsigned vo = (((unsigned)piece * 8u + (unsigned)lrow) * (unsigned)(9 * Cin) + (unsigned)chunk * 8u) * 2u;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(bh + vo), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
+                dma_piece(bh + vo, Bdst + piece * 1024);
             }
             return;
         }
+        // (Measured and dropped, round 3: the tile moved by waves 0-3 or 0-1 only, so that the two waves of a SIMD stop issuing their
+        // DMA pieces at the same time: 1 % slower (tools/conv_ab_r3.py, same box) — and in that form the compiler no longer
+        // drained vmcnt in front of the loop's barrier, hence the explicit wait there.  The scalar-base form above for both planes:
+        // no spills any more, 8 vector instructions fewer per tap, no measurable change.)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int piece = wu * 2 + k;
             const size_t off = ((size_t)(n0 + piece * 8 + lrow) * 9 + tap) * Cin + c0 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.whi + off), (lds_ptr_t)(Bdst + piece * 1024), 16, 0, 0);
-            if constexpr (TWO) __builtin_amdgcn_global_load_lds((glb_ptr_t)(p.wlo + off), (lds_ptr_t)(Bdst + 16384 + piece * 1024), 16, 0, 0);
+            dma_piece(p.whi + off, Bdst + piece * 1024);
+            if constexpr (TWO) dma_piece(p.wlo + off, Bdst + 16384 + piece * 1024);
         }
     };
     // X8: E8M0 block scales of the cross-term MFMA.  Block b of its K = 128 takes the scale byte of lane group b: blocks
@@ -827,6 +855,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             store_window();
             {   // first tap of the slab: its tile is on its way by DMA (issued during the previous slab / before the loop)
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                dma_drain();
                 __syncthreads();
                 dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_b(fa, Bcur, 0);
@@ -840,8 +869,11 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 mma_rows(fa, 0, IB);
                 if (tap < 8) read_a(fa, tap + 1, 0);    // same window: no need to wait for the barrier
                 mma_rows(fb, 0, 2);
+                // (round 3: forcing the fragment reads between these MFMAs with sched_group_barrier, as in the split8 loop below,
+                // costs the fp16 mode 1.7 % — 16 spilled registers — tools/_diag/f16_lib_ab.py)
                 if (tap < 8) {
-                    __syncthreads();           // the next tap's tile has landed (DMA issued one tap ago, drained by this barrier's wait)
+                    dma_drain();
+                    __syncthreads();           // the next tap's tile has landed (DMA issued one tap ago, drained just above)
                     // the tile after next goes into the buffer this tap has finished reading
                     if (tap < 7) dma_b(Bcur, tap + 2, c0);
                     else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
@@ -916,12 +948,22 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             store_window();
             {
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
+                dma_drain();
                 __syncthreads();
                 DASV_STAMP(4 + 4 * (sl - sl_lo));
                 dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_f16_b(bh0, Bcur, 0);
                 read_f16_a(ah0, 0, 0);
             }
+#ifndef DASV_X8_SCHED
+#define DASV_X8_SCHED 1   // 0: the scheduler's own order (A/B with tools/conv_ab_r3.py: the hints are worth 1-2 % over the seven layers)
+#endif
+            // (Measured and dropped, round 3, same-box A/B with tools/conv_ab_r3.py: the tap as a HAND-ORDERED stream — every MFMA and
+            // every fragment read pinned in place with sched_barrier, one read behind each MFMA of the group in front of its consumer,
+            // counted lgkmcnt waits only, the tile's DMA branch-free — runs within 0.1 % of the hinted order below; the same stream with
+            // the two waves of a SIMD issuing their DMA pieces at different points of the tap (per-role copies of the loop) spills
+            // inside the loop and is 24 % slower.  The tap is not waiting for fragment reads: SQ counters over these launches give
+            // 32 % of the wave cycles issuing, 36 % stalled at issue behind the busy matrix pipe, 33 % parked at waits and barriers.)
             for (int tap = 0; tap < 9; ++tap, ++it) {
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
                 char* Bnxt = Bbase + ((it & 1) ? 0 : 32768);
@@ -932,7 +974,25 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 mma_f16(bh1, ah1);
                 if (tap < 8) read_f16_a(ah0, tap + 1, 0);
                 mma_e4m3(0, 2);
+#if DASV_X8_SCHED == 1
+                // the tap's fragment reads go out BETWEEN the MFMAs of the groups in front of their consumers: one read behind each
+                // of the 16 first-half MFMAs (second-half fp16 fragments, then the weight e4m3 fragments), one per two MFMAs
+                // after that (pixel e4m3 fragments; the next tap's first-half pixel fragments beside the e4m3 group).  Left alone
+                // the scheduler emits each group as a block behind a block of reads and an lgkmcnt(0): both waves of a SIMD read,
+                // then both multiply
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#endif
                 if (tap < 8) {
+                    dma_drain();
                     __syncthreads();
                     if (tap < 7) dma_b(Bcur, tap + 2, c0);
                     else if (sl + 1 < nslab) dma_b(Bcur, 0, c0 + CBK);
@@ -1475,7 +1535,7 @@ int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* 
 
 #if DASV_CONV_STAMPS
 int dasv_debug_conv_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasv::dasv_conv_stamps), sizeof(unsigned long long) * 64);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dasv::dasv_conv_stamps), sizeof(unsigned long long) * 128);
 }
 #endif
 

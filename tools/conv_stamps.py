@@ -16,7 +16,7 @@ from doubleattentionspeakerverification_amd import conv as hc
 lib = ctypes.CDLL(SO)
 vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 lib.dasv_conv3x3_bias_relu_x8_nhwc.restype = ci
-lib.dasv_conv3x3_bias_relu_x8_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, sz, ci, ci, ci, ci, ci, ci, vp]
+lib.dasv_conv3x3_bias_relu_x8_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, sz, ci, ci, ci, ci, ci, ci, vp]
 lib.dasv_debug_conv_stamps.restype = ci
 lib.dasv_debug_conv_stamps.argtypes = [vp]
 dev = torch.device("cuda:0")
@@ -26,16 +26,18 @@ layers = [("conv12", 128, 128, 300, 80), ("conv21", 128, 256, 150, 40), ("conv22
 stream = torch.cuda.current_stream().cuda_stream
 for name, cin, cout, H, W in layers:
     xf = torch.relu(torch.randn(B, cin, 2 * H, 2 * W, device=dev)).contiguous(memory_format=torch.channels_last)
-    x = hc.maxpool2x2_ceil(xf, pack=True)
+    recs = hc.new_ranges(dev, 3)
+    recs[0] = hc.range_of(xf)
+    x = hc.maxpool2x2_ceil(xf, pack=True, x_rec=recs[0], y_rec=recs[1])
     del xf
     w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
     b = torch.randn(cout, device=dev) * 0.1
-    hi, lo = hc.PackedConvWeights().get(w, "split8")
+    hi, lo = hc.PackedConvWeights().get(w, "split8", b)
     y = torch.zeros(B, H, W, cout, device=dev)
 
     def run():
-        assert lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 1, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), 1, None, 0,
-                                                  B, H, W, cin, cout, 1, stream) == 0
+        assert lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), 1, recs[1].data_ptr(), hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), 1,
+                                                  recs[2].data_ptr(), None, 0, B, H, W, cin, cout, 1, stream) == 0
     for _ in range(3): run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,7 +45,7 @@ for name, cin, cout, H, W in layers:
     for _ in range(5): run()
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
-    st = (ctypes.c_ulonglong * 64)()
+    st = (ctypes.c_ulonglong * 128)()
     assert lib.dasv_debug_conv_stamps(st) == 0
     t = [int(v) for v in st]
     tbm = 192 if W > 40 else 256
@@ -57,4 +59,12 @@ for name, cin, cout, H, W in layers:
         line += " | slab%d: load+wait %.2f store+sync %.2f taps %.2f" % (sl, us(k, k + 1), us(k + 1, k + 2), us(k + 2, k + 3))
     last = 2 + 4 * (nslab - 1) + 3 if nslab <= 14 else None
     line += " | loop total %.2f | epi: wait %.2f image %.2f stores %.2f | tile total %.2f" % (us(1, 60), us(60, 61), us(61, 62), us(62, 63), us(0, 63))
+    # the clock the CU held over the tile: shader cycles (slots 64+) per 100 MHz tick; and the matrix pipe's share of those cycles
+    # (two waves per SIMD, each IB x 4 tiles x (2 x 16 + 32) cycles per tap)
+    cyc = t[64 + 63] - t[64 + 0]
+    ghz = cyc / max(1, t[63] - t[0]) * 0.1
+    mfma = 2 * (tbm // 64) * 4 * 64 * 9 * nslab
+    line += " | clock %.2f GHz, tile %d cycles, matrix pipe %d = %.0f %%" % (ghz, cyc, mfma, 100.0 * mfma / cyc)
+    lc = t[64 + 60] - t[64 + 1]
+    line += " (loop alone %d cycles: %.0f %%)" % (lc, 100.0 * mfma / max(1, lc))
     print(line, flush=True)
