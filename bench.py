@@ -239,6 +239,61 @@ def pmc_traffic(workload, dtype):
         return None
 
 
+def conv_power_probe(dev, B):
+    """Does the chip's power management hold the split8 convolution back?  One layer of the default model (conv32: 512 -> 512 on
+    [B,75,20]) launched on random ReLU activations / random weights and on ALL-ZERO activations and weights: same instruction
+    stream, same addresses and traffic, but the matrix pipe draws far less on zeros.  A launch that finishes sooner on zeros was
+    running at a lowered clock (MI355X_MICROARCH.md, 'DVFS give-back'); its roofline fraction against the 2.4 GHz peak cannot
+    reach what a kernel limited by its own stalls could.  (tools/_diag/conv_power_test.py: the four wide layers.)"""
+    import torch
+    from doubleattentionspeakerverification_amd import _lib, conv as hc
+    lib = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    cin = cout = 512
+    H, W = 75, 20
+    g = torch.Generator(device=dev).manual_seed(7)
+    runs, keep = {}, []
+    for tag in ("random", "zeros"):
+        xf = torch.relu(torch.randn(B, 2 * H, 2 * W, cin, device=dev, generator=g))
+        w = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, device=dev, generator=g) * 0.1
+        if tag == "zeros":
+            xf.zero_()
+            w.zero_()
+        recs = hc.new_ranges(dev, 3)
+        if tag == "random":
+            recs[0] = hc.range_of(xf)
+        xn = torch.empty(B, H, W, cin, device=dev)
+        _lib.check(lib.dasv_maxpool2x2_ceil_x8_nhwc(xf.data_ptr(), recs[0].data_ptr(), xn.data_ptr(), recs[1].data_ptr(), B, 2 * H, 2 * W, cin, st),
+                   "dasv_maxpool2x2_ceil_x8_nhwc")
+        wh, wl = hc.PackedConvWeights().get(w, "split8", b)
+        y = torch.empty(B, H, W, cout, device=dev)
+        keep.append((xn, wh, wl, b, y, recs))
+
+        def run(xn=xn, wh=wh, wl=wl, b=b, y=y, recs=recs):
+            _lib.check(lib.dasv_conv3x3_bias_relu_x8_nhwc(xn.data_ptr(), 1, recs[1].data_ptr(), wh.data_ptr(), wl.data_ptr(), b.data_ptr(),
+                                                          y.data_ptr(), 0, recs[2].data_ptr(), None, 0, B, H, W, cin, cout, 1, st),
+                       "dasv_conv3x3_bias_relu_x8_nhwc")
+        runs[tag] = run
+        del xf
+    best = {"random": 1e9, "zeros": 1e9}
+    for rnd in range(4):
+        for tag in (("random", "zeros") if rnd % 2 == 0 else ("zeros", "random")):
+            for _ in range(5):
+                runs[tag]()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                runs[tag]()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            best[tag] = min(best[tag], e0.elapsed_time(e1) / 20)
+    return {"layer": "conv32 split8, 512->512 on [%d,75,20], packed input" % B, "ms_random_data": round(best["random"], 4),
+            "ms_all_zero_data": round(best["zeros"], 4), "zero_over_random": round(best["zeros"] / best["random"], 4),
+            "reading": "same launches, same instruction stream and traffic: the share by which zeros finish sooner is clock the chip "
+                       "withholds on real data"}
+
+
 def mfma_util_pmc():
     """Matrix-pipe busy share of the conv kernels from the committed `rocprofv3 --pmc MfmaUtil` passes (profiles/)."""
     try:
@@ -599,6 +654,8 @@ def main():
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
                         "mfma_util_pmc_percent": mfma_util_pmc()}
+            if world == 1 and args.workload == "embed" and args.conv == "split8":
+                roofline["power_probe"] = conv_power_probe(dev, B)
         # companions (never the headline `value`): the same step with the other operand modes of the convolutions, each with its
         # measured embedding error against the CPU oracle's fp32 embeddings of the same batch
         companions = None

@@ -61,6 +61,7 @@ SIGNATURES = {
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_wgrad_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_wgrad_x8_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

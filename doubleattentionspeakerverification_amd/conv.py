@@ -23,10 +23,11 @@ __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights"
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
 # "split8": fp32-grade on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8).  Its
 # operand planes have fp16's / e4m3's exponent range, which is why round 2 kept gradients on the split-bf16 kernel; with every
-# tensor scaled by its range record the DATA gradient runs in split8 too (DGRAD_MODE); the weight gradient (its own kernel,
-# csrc/conv3x3_wgrad.hip) stays split-bf16.
+# tensor scaled by its range record the DATA gradient runs in split8 too (DGRAD_MODE), and since round 3 the WEIGHT gradient as well
+# (WGRAD_MODE; its own kernel, csrc/conv3x3_wgrad.hip X8).
 BACKWARD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split"}
 DGRAD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split8"}
+WGRAD_MODE = {"split": "split", "bf16": "bf16", "fp16": "bf16", "split8": "split8"}
 _PACK_KIND = {"split": 0, "bf16": 0, "fp16": 1, "split8": 2}
 USE_HIP_WGRAD = True   # weight gradients on the hand-written kernel (False: ATen / MIOpen)
 
@@ -193,9 +194,11 @@ def supported_wgrad(cin, cout, width=1, pixels=0):
     return cin % 64 == 0 and cout % 64 == 0 and width <= 80 and pixels * max(cin, cout) * 4 < 0xffffffff
 
 
-def conv3x3_wgrad(x, g, mode="split"):
+def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None):
     """Weight gradient [Cout,Cin,3,3] of conv3x3 (stride 1, pad 1) from x [B,Cin,H,W] and g [B,Cout,H,W]
-    (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip)."""
+    (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip).
+    mode "split8": fp16 products + block-scaled e4m3 cross terms; x_rec / g_rec are the operands' range records (an upper bound
+    of max |v| is enough; measured here with one pass over the tensor when None)."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = g.shape[1]
@@ -206,6 +209,14 @@ def conv3x3_wgrad(x, g, mode="split"):
     gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
     nbytes = lib.dasv_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    if mode == "split8":
+        x_rec = range_of(x) if x_rec is None else x_rec
+        g_rec = range_of(g) if g_rec is None else g_rec
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_wgrad_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), g_rec.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+                                                nbytes, B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_wgrad_x8_nhwc")
+        return gw
     with torch.cuda.device(x.device):
         rc = lib.dasv_conv3x3_wgrad_nhwc(MODES[mode], x.data_ptr(), g.data_ptr(), gw.data_ptr(), ws.data_ptr(), nbytes,
                                          B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
@@ -222,8 +233,11 @@ class _ConvReLUFn(torch.autograd.Function):
         cin_x, cout_p = x.shape[1], padded_channels(cout)
         hi, lo = packed.get(weight, mode, bias, (cin_x, cout_p))
         bias_k = packed.bias if (cin_x, cout_p) != (cin, cout) and bias is not None else bias
+        if mode == "split8" and x_rec is None:
+            x_rec = range_of(x)
         y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec)
         ctx.save_for_backward(x, weight, y)
+        ctx.x_rec = x_rec           # (split8) the weight gradient scales x by the same record
         ctx.has_bias = bias is not None
         ctx.mode = mode
         ctx.grad_premasked = grad_premasked
@@ -275,7 +289,10 @@ class _ConvReLUFn(torch.autograd.Function):
             want_x = False
         gw = gb = None
         if want_w and USE_HIP_WGRAD and supported_wgrad(cin_x, cout_p, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
-            gw = conv3x3_wgrad(x, g, bmode)
+            wmode = WGRAD_MODE[ctx.mode]
+            # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
+            gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
+                               g_rec=getattr(gy, "_dasv_rec", None) if wmode == "split8" else None)
             if padded:
                 gw = gw[:cout, :cin].contiguous()
             want_w = False

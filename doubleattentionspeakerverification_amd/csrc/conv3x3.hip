@@ -848,6 +848,12 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
         // behind its second-half MFMAs, where half of the fragment registers are dead — tools/conv_stamps.py shows ~1.2 us of global
         // latency exposed at every slab top.  The 256-pixel variants spill 32-44 registers for it and run 7-20 % slower; the
         // 192-pixel ones fit and gain nothing measurable.)
+        // (Measured and dropped, round 3: in the one-plane modes a tap's tile is 16 KB, so a 32-KB buffer can take TWO taps and the
+        // workgroup then meets at four tile barriers per slab instead of eight — stages {0,1} {2,3} {4,5} {6,7} {8}, bit-identical,
+        // and 1.0 % SLOWER over the seven layers (tools/_diag/f16_lib_ab.py; 4 % slower with the pair loop kept rolled).  Like every
+        // other change of the tap's schedule this round it moves nothing, because these launches run against the chip's power
+        // management, not against their own stalls: tools/_diag/conv_power_test.py — the same launches on all-zero data, same
+        // instruction stream and traffic, finish 10-18 % sooner, and the in-kernel clock reads 1.9-2.0 GHz of 2.4 on real data.)
         for (int sl = sl_lo; sl < nslab; ++sl) {
             const int c0 = sl * CBK;
             load_window(xrun + c0);

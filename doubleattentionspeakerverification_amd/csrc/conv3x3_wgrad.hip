@@ -75,6 +75,9 @@ struct WgradParams {
     int magic_w;        // floor(65536 / W) + 1: (v * magic_w) >> 16 == v / W for v * W < 65536
     int hcarries;       // image-row carries a 16-position step of the window walk can cause: ceil((16/(W+1) + 1) / (H+1))
     int patch;          // 1: chunks are 8 x 8 pixel patches (W % 8 == 0); chunks_per_image = ceil(H/8) * (W/8)
+    int ph;             // patch == 2: whole image rows per chunk (64 / W)
+    const uint32_t* x_rec;   // X8: range records of x and g (dasv_hip.h): [0] = bits of max |v|
+    const uint32_t* g_rec;
 };
 
 __host__ __device__ inline int wgrad_xrows(int W) { return WKC + WKC / W + 2 + 2 * (W + 2) + 1; }
@@ -84,6 +87,9 @@ __host__ __device__ inline int wgrad_xrows(int W) { return WKC + WKC / W + 2 + 2
 // producer/consumer kernel, both layouts in one run: consumers alone 1.5 % faster, the full kernel 3 % slower — the plain
 // layout stays.
 __device__ __forceinline__ int wg_off(int row, int seg) { return row * 128 + (seg << 5); }
+// e4m3 planes (X8): 64-byte rows of four 16-byte channel blocks.  A transposed read's 16 lanes address 8 consecutive rows x 16 bytes:
+// rows r and r + 4 share their banks, so the block index is XORed with (row >> 2) & 3 (rows r, r + 4 then land in different blocks)
+__device__ __forceinline__ int w8_off(int row, int blk) { return row * 64 + ((blk ^ ((row >> 2) & 3)) << 4); }
 
 // transposed fragment: 8 consecutive K rows (two 4-row blocks) of a 16-column block; `p0`/`p1` are this lane's row addresses
 __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
@@ -110,7 +116,20 @@ __host__ __device__ constexpr size_t wgrad_buffer_bytes(int nx) {
 // the 10 x 10 patch around it (100 rows instead of 64 + 2 W + ... = 231 for an 80-column map), window row of patch pixel
 // (jy, jx) is (jy+1)*10 + jx+1 and a tap is a shift by dy*10 + dx — no table, no pad columns (pixels outside the image are
 // fetched as zeros) — and a producer thread's row offsets inside the patch are constants of the launch.
-template <bool SPLIT, int NX, bool PATCH>
+// X8 (the fp16 + e4m3 form of the forward kernel's `split8` mode, csrc/conv3x3.hip): g = (gh + gl) 2^-Eg, x = (xh + xl) 2^-Ex with fp16
+// gh, xh and the scales from the tensors' range records; gh xh on the fp16 MFMA, both cross terms of a 64-pixel chunk on ONE block-scaled
+// e4m3 MFMA (K = 128 = 64 pixels of e4m3(g) e4m3(xl 2^12) | 64 pixels of e4m3(gl 2^12) e4m3(x)): 64 matrix-pipe cycles per 16 x 16 x 64
+// instead of the 96 of three bf16 MFMAs.  The hi planes keep their place in the buffers; each lo plane's room holds the two e4m3 planes
+// ([row][64 channels] bytes), which the consumers fetch with ds_read_b64_tr_b8 (tools/tr8_check.hip: in a group of 16 lanes, byte k of
+// lane d comes from the 8 bytes addressed by lane 2k + (d >> 3), byte d & 7 — so lanes 2k / 2k + 1 address channels 0-7 / 8-15 of
+// pixel k, and every lane receives eight consecutive pixels of its own channel).
+//
+// PATCH == 2 (ROWS; narrow maps whose width is not a multiple of 8): a chunk is `ph` = 64 / W whole image rows (ph W <= 64 pixels, the
+// rest of the 64 are dummies with g = 0).  Its window is the (ph + 2) x (W + 2) block around them — window row of chunk pixel j is
+// (j / W + 1)(W + 2) + j % W + 1, a tap a shift by dy (W + 2) + dx — so, like the patches, no table and no carried coordinates:
+// a producer thread's window positions are constants of the launch.  For the 20- and 10-column maps of the default model the
+// raster form's producers (coordinate carries per fetched row, 114 / 97 window rows) were what the fp16 + e4m3 consumers waited for.
+template <bool SPLIT, int NX, int PATCH, bool X8 = false>
 __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, H = p.H, Cin = p.Cin, Cout = p.Cout;
@@ -137,6 +156,14 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
     const int chunk_hi = min(total_chunks, chunk_lo + p.chunks_per_split);
     const int nch = chunk_hi - chunk_lo;
     const int tid = threadIdx.x;
+    // X8: power-of-two scales from the range records (wave-uniform): max |v| 2^E in [128, 256)
+    float sg = 1.f, sx = 1.f, sout = 1.f;
+    if constexpr (X8) {
+        const int Eg = x8_exp_for(p.g_rec[0]), Ex = x8_exp_for(p.x_rec[0]);
+        sg = x8_pow2(Eg);
+        sx = x8_pow2(Ex);
+        sout = x8_pow2(-Eg > -126 ? -Eg : -126) * x8_pow2(-Ex > -126 ? -Ex : -126);
+    }
 
     if (tid >= 256) {
         // ------------------------------------------------------------------ producers
@@ -161,12 +188,21 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
         // r = srow + 16k -> (u, v) = (r / 10, r % 10), constants of the launch
         int pu[NX], pv[NX];
         unsigned poff[NX];
-        if constexpr (PATCH) {
+        if constexpr (PATCH == 1) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) {
                 const int r = srow + 16 * k;
                 pu[k] = r / 10;
                 pv[k] = r - pu[k] * 10;
+                poff[k] = (unsigned)(pu[k] * W + pv[k]) * x_rowbytes;
+            }
+        }
+        if constexpr (PATCH == 2) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const int r = srow + 16 * k;
+                pu[k] = r / (W + 2);
+                pv[k] = r - pu[k] * (W + 2);
                 poff[k] = (unsigned)(pu[k] * W + pv[k]) * x_rowbytes;
             }
         }
@@ -176,12 +212,14 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
         // (wave-uniform scalar adds) instead of being divided out again each time.
         int cb = chunk_lo / p.chunks_per_image;                 // utterance of the next chunk to fetch
         int cpi = chunk_lo - cb * p.chunks_per_image;           // its index inside the utterance
-        int ch0 = PATCH ? (cpi / patches_per_row) * 8 : (cpi * WKC) / W;                     // first row
-        int cw0 = PATCH ? (cpi - (cpi / patches_per_row) * patches_per_row) * 8 : cpi * WKC - ((cpi * WKC) / W) * W;   // first column
+        int ch0 = PATCH == 2 ? cpi * p.ph : PATCH ? (cpi / patches_per_row) * 8 : (cpi * WKC) / W;                     // first row
+        int cw0 = PATCH == 2 ? 0 : PATCH ? (cpi - (cpi / patches_per_row) * patches_per_row) * 8 : cpi * WKC - ((cpi * WKC) / W) * W;   // first column
         const int dh64 = WKC / W, dw64 = WKC - dh64 * W;        // raster: 64 pixels = dh64 rows + dw64 columns
         auto advance = [&]() {
             if (++cpi == p.chunks_per_image) { cpi = 0; ++cb; ch0 = 0; cw0 = 0; return; }
-            if constexpr (PATCH) {
+            if constexpr (PATCH == 2) {
+                ch0 += p.ph;
+            } else if constexpr (PATCH == 1) {
                 cw0 += 8;
                 if (cw0 >= W) { cw0 = 0; ch0 += 8; }
             } else {
@@ -191,7 +229,26 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
             }
         };
         auto fetch = [&](int) {
-            if constexpr (PATCH) {
+            if constexpr (PATCH == 2) {
+                const int b = cb, h0 = ch0;
+                advance();
+                const int npx = min(p.ph, H - h0) * W;            // real pixels of the chunk: whole rows, raster-contiguous
+                const unsigned gbase = (unsigned)((b * H + h0) * W) * g_rowbytes + g_thread;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned o = srow + 16 * k < npx ? gbase + (unsigned)(16 * k) * g_rowbytes : g_bytes;
+                    gr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)o, 0, 0));
+                }
+                // window origin = pixel (h0 - 1, -1)
+                const unsigned xbase = (unsigned)((b * H + h0 - 1) * W - 1) * x_rowbytes + x_thread;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) {
+                    const bool ok = ((unsigned)(h0 - 1 + pu[k]) < (unsigned)H) & ((unsigned)(pv[k] - 1) < (unsigned)W) & (pu[k] < p.ph + 2);
+                    xr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(ok ? xbase + poff[k] : x_bytes), 0, 0));
+                }
+                return;
+            }
+            if constexpr (PATCH == 1) {
                 const int b = cb, h0 = ch0, w0 = cw0;
                 advance();
                 const unsigned gbase = (unsigned)((b * H + h0) * W + w0) * g_rowbytes + g_thread_patch;
@@ -275,23 +332,37 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 uint32_t h0_, l0_, h1_, l1_;
-                wsplit2(gr[k][0], gr[k][1], h0_, l0_);
-                wsplit2(gr[k][2], gr[k][3], h1_, l1_);
                 const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                if constexpr (X8) {
+                    cvt4_x8(gr[k], sg, h0_, h1_, l0_, l1_);
+                    const int o8 = w8_off(srow + 16 * k, scc >> 2) + (scc & 3) * 4;
+                    *reinterpret_cast<uint32_t*>(Glo + o8) = l0_;                       // e4m3(g)
+                    *reinterpret_cast<uint32_t*>(Glo + WKC * 64 + o8) = l1_;            // e4m3(gl 2^12)
+                } else {
+                    wsplit2(gr[k][0], gr[k][1], h0_, l0_);
+                    wsplit2(gr[k][2], gr[k][3], h1_, l1_);
+                    if (SPLIT) *reinterpret_cast<uint2*>(Glo + o) = make_uint2(l0_, l1_);
+                }
                 *reinterpret_cast<uint2*>(Ghi + o) = make_uint2(h0_, h1_);
-                if (SPLIT) *reinterpret_cast<uint2*>(Glo + o) = make_uint2(l0_, l1_);
             }
 #pragma unroll
             for (int k = 0; k < NX; ++k) {
                 uint32_t h0_, l0_, h1_, l1_;
-                wsplit2(xr[k][0], xr[k][1], h0_, l0_);
-                wsplit2(xr[k][2], xr[k][3], h1_, l1_);
                 const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                if constexpr (X8) {
+                    cvt4_x8(xr[k], sx, h0_, h1_, l0_, l1_);
+                    const int o8 = w8_off(srow + 16 * k, scc >> 2) + (scc & 3) * 4;
+                    *reinterpret_cast<uint32_t*>(Xlo + o8) = l0_;                       // e4m3(x)
+                    *reinterpret_cast<uint32_t*>(Xlo + xplane / 2 + o8) = l1_;          // e4m3(xl 2^12)
+                } else {
+                    wsplit2(xr[k][0], xr[k][1], h0_, l0_);
+                    wsplit2(xr[k][2], xr[k][3], h1_, l1_);
+                    if (SPLIT) *reinterpret_cast<uint2*>(Xlo + o) = make_uint2(l0_, l1_);
+                }
                 *reinterpret_cast<uint2*>(Xhi + o) = make_uint2(h0_, h1_);
-                if (SPLIT) *reinterpret_cast<uint2*>(Xlo + o) = make_uint2(l0_, l1_);
             }
             // chunk pixel j -> window row (every image-row end crossed adds one pad position)
-            if (!PATCH && ptid < WKC) Ltab[ptid] = ptid + (int)(((unsigned)(w0_next + ptid) * (unsigned)p.magic_w) >> 16) + (W + 2);
+            if (PATCH == 0 && ptid < WKC) Ltab[ptid] = ptid + (int)(((unsigned)(w0_next + ptid) * (unsigned)p.magic_w) >> 16) + (W + 2);
         };
 
         if (nch > 0) {
@@ -320,12 +391,96 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // window row of chunk pixel j (PATCH 1: 10 x 10 window of an 8 x 8 patch; PATCH 2: (ph + 2) x (W + 2) window of ph whole rows, a dummy
+    // pixel behind them borrows pixel 0's row — its g is zero; raster: the chunk's table)
+    const int tstride = PATCH == 1 ? 10 : PATCH == 2 ? W + 2 : W + 1;
+    auto wrow = [&](int j, const int* Ltab) {
+        if constexpr (PATCH == 1) return (j >> 3) * 10 + (j & 7) + 11;
+        else if constexpr (PATCH == 2) {
+            const int jy = (int)(((unsigned)j * (unsigned)p.magic_w) >> 16);      // j / W (j < 64 <= 65536 / W)
+            return j < p.ph * W ? (jy + 1) * (W + 2) + (j - jy * W) + 1 : W + 3;
+        } else return Ltab[j];
+    };
     __syncthreads();
     for (int ci = 0; ci < nch; ++ci) {
         const char* Ghi = smem + (ci & 1) * bufsz;
         const char* Glo = Ghi + WKC * 128;
         const char* Xhi = Glo + WKC * 128;
         const int* Ltab = reinterpret_cast<const int*>(Xhi + 2 * xplane);
+        if constexpr (X8) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            typedef i32x2 __attribute__((address_space(3))) * lds2;
+            // (window rows of the pixels this lane addresses in the e4m3 section: fetched here, ahead of the fp16 section, so that the table
+            // read's latency is not in front of the first transposed reads there)
+            const int s16 = lane & 15;
+            const int pA = 16 * grp + (s16 >> 1), pB = pA + 8;
+            const int rA = wrow(pA, Ltab), rB = wrow(pB, Ltab);
+            // ---- gh xh: two K steps of 32 pixels on the fp16 MFMA (the bf16 loop below, one plane)
+#pragma unroll
+            for (int k0 = 0; k0 < WKC; k0 += 32) {
+                const int j0 = k0 + 8 * grp + q, j1 = j0 + 4;
+                const int col = 4 * pp * 2;
+                bf16x8 gh[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gh[i] = tr_frag(Ghi + wg_off(j0, i) + col, Ghi + wg_off(j1, i) + col);
+                const int r0 = wrow(j0, Ltab), r1 = wrow(j1, Ltab);
+                auto xfrag = [&](int t) {
+                    const int toff = (t / 3 - 1) * tstride + (t % 3 - 1);
+                    return tr_frag(Xhi + wg_off(r0 + toff, wv) + col, Xhi + wg_off(r1 + toff, wv) + col);
+                };
+                bf16x8 xh[2];
+                xh[0] = xfrag(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 1 < 9) xh[(t + 1) & 1] = xfrag(t + 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, gh[i]), __builtin_bit_cast(f16x8, xh[t & 1]),
+                                                                           acc[i][t], 0, 0, 0);
+                }
+            }
+            // ---- both cross terms of the chunk: one K = 128 block-scaled e4m3 MFMA per tile.  A lane's registers 0-3 are pixels
+            // 16 grp ... 16 grp + 15 of term one (e4m3(g) x e4m3(xl 2^12)), registers 4-7 the same pixels of term two
+            // (e4m3(gl 2^12) x e4m3(x)); MX block b takes its E8M0 scale from lane group b: blocks 0, 1 are term one, 2, 3 term two
+            {
+                const int hb = (s16 & 1) * 8;                                // pA, pB: the pixels this lane ADDRESSES (see tr8 above)
+                const char* G8 = Glo;                                        // e4m3(g) | e4m3(gl 2^12), [64][64] bytes each
+                const char* X8v = Xhi + xplane;                              // e4m3(x) | e4m3(xl 2^12), [16 NX][64] bytes each
+                auto tr8 = [&](const char* a0, const char* a1, const char* b0, const char* b1) {
+                    const i32x2 u0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2)a0), u1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2)a1);
+                    const i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2)b0), v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds2)b1);
+                    return i32x8{u0[0], u0[1], u1[0], u1[1], v0[0], v0[1], v1[0], v1[1]};
+                };
+                i32x8 g8[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* a = G8 + hb;
+                    const int oA = w8_off(pA, i), oB = w8_off(pB, i);
+                    g8[i] = tr8(a + oA, a + oB, a + WKC * 64 + oA, a + WKC * 64 + oB);
+                }
+                const int gsc = grp < 2 ? 127 : 127 - X8_ACT_SHIFT, xsc = grp < 2 ? 127 - X8_ACT_SHIFT : 127;
+                auto xfrag8 = [&](int t) {
+                    const int toff = (t / 3 - 1) * tstride + (t % 3 - 1);
+                    const char* a = X8v + hb;
+                    const int oA = w8_off(rA + toff, wv), oB = w8_off(rB + toff, wv);
+                    // term one wants the residual plane, term two the value plane
+                    return tr8(a + xplane / 2 + oA, a + xplane / 2 + oB, a + oA, a + oB);
+                };
+                i32x8 x8[2];
+                x8[0] = xfrag8(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t + 1 < 9) x8[(t + 1) & 1] = xfrag8(t + 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(g8[i], x8[t & 1], acc[i][t], 0, 0, 0, gsc, 0, xsc);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- MFMA: two K steps of 32 pixels; the fragments of tap t+1 are requested before tap t's MFMAs issue
 #pragma unroll
         for (int k0 = 0; k0 < (DASV_WGRAD_DIAG == 2 ? 0 : WKC); k0 += 32) {
@@ -338,10 +493,9 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
                 gh[i] = tr_frag(Ghi + o0, Ghi + o1);
                 if (SPLIT) gl[i] = tr_frag(Glo + o0, Glo + o1);
             }
-            const int r0 = PATCH ? (j0 >> 3) * 10 + (j0 & 7) + 11 : Ltab[j0];
-            const int r1 = PATCH ? (j1 >> 3) * 10 + (j1 & 7) + 11 : Ltab[j1];
+            const int r0 = wrow(j0, Ltab), r1 = wrow(j1, Ltab);
             auto xfrag = [&](int t, bf16x8& xh, bf16x8& xl) {
-                const int toff = (t / 3 - 1) * (PATCH ? 10 : W + 1) + (t % 3 - 1);
+                const int toff = (t / 3 - 1) * tstride + (t % 3 - 1);
                 const char* x0 = Xhi + wg_off(r0 + toff, wv) + col;
                 const char* x1 = Xhi + wg_off(r1 + toff, wv) + col;
                 xh = tr_frag(x0, x1);
@@ -373,7 +527,7 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + i * 16 + (lane >> 4) * 4 + r;
-                p.part[(((size_t)split * Cout + n) * 9 + t) * Cin + c0 + wv * 16 + (lane & 15)] = acc[i][t][r];
+                p.part[(((size_t)split * Cout + n) * 9 + t) * Cin + c0 + wv * 16 + (lane & 15)] = X8 ? acc[i][t][r] * sout : acc[i][t][r];
             }
 }
 
@@ -392,14 +546,23 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce(const float* __restr
     }
 }
 
-static void wgrad_plan(int B, int H, int W, int Cin, int Cout, WgradParams& p) {
+static void wgrad_plan(int B, int H, int W, int Cin, int Cout, WgradParams& p, bool x8) {
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.ctiles = Cin / 64; p.ntiles = Cout / 64;
 #ifndef DASV_WGRAD_RASTER
 #define DASV_WGRAD_RASTER 0   // timing builds only (tools/wgrad_diag.py): 1 forces raster chunks
 #endif
     p.patch = (W % 8 == 0 && !DASV_WGRAD_RASTER) ? 1 : 0;
-    p.chunks_per_image = p.patch ? ((H + 7) / 8) * (W / 8) : (H * W + WKC - 1) / WKC;
+    // whole-row chunks: at least 3/4 of the 64 chunk positions real pixels, window within the widest staging variant
+    p.ph = W <= WKC ? WKC / W : 0;
+    // (measured, tools/_diag/wgrad_x8_ab.py: the fp16 + e4m3 consumers gain from it on every narrow layer — 38 x 10: -12 %, 75 x 20:
+    // -24 % against raster chunks — the split-bf16 ones only where it does not add chunks: 75 x 20 -4 %, 38 x 10 (7 chunks per
+    // utterance instead of 6) +6 %)
+    const int rows_chunks = p.ph >= 1 ? (H + p.ph - 1) / p.ph : 0, raster_chunks = (H * W + WKC - 1) / WKC;
+    if (!p.patch && !DASV_WGRAD_RASTER && p.ph >= 1 && p.ph * W * 4 >= WKC * 3 && (p.ph + 2) * (W + 2) <= 16 * 10 &&
+        (x8 || rows_chunks * 16 <= raster_chunks * 17))
+        p.patch = 2;
+    p.chunks_per_image = p.patch == 2 ? (H + p.ph - 1) / p.ph : p.patch ? ((H + 7) / 8) * (W / 8) : (H * W + WKC - 1) / WKC;
     const int total = B * p.chunks_per_image, tiles = p.ctiles * p.ntiles;
     // workgroups per launch the pixel range is split for: one workgroup per CU is resident, so whole multiples of 256 avoid a
     // partial last round; measured sweep over the VGG4L/1024 layers (tools/_diag/wgrad_target_sweep.py, interleaved):
@@ -413,7 +576,7 @@ static void wgrad_plan(int B, int H, int W, int Cin, int Cout, WgradParams& p) {
     if (S < 1) S = 1;
     p.chunks_per_split = (total + S - 1) / S;
     p.S = (total + p.chunks_per_split - 1) / p.chunks_per_split;
-    p.xrows = wgrad_xrows(W);
+    p.xrows = p.patch == 2 ? (p.ph + 2) * (W + 2) : wgrad_xrows(W);
     // the per-lane division by W (window-row table) has numerators below W + 64 and W <= 80: numerator * W < 65536, where
     // the multiply-shift form is exact
     p.magic_w = 65536 / W + 1;
@@ -426,47 +589,74 @@ extern "C" {
 
 size_t dasv_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return 0;
-    dasv::WgradParams p;
-    dasv::wgrad_plan(B, H, W, Cin, Cout, p);
-    return (size_t)p.S * Cout * 9 * Cin * sizeof(float);
+    dasv::WgradParams p, q;     // (the chunk form, and with it the split count, may differ between the operand modes)
+    dasv::wgrad_plan(B, H, W, Cin, Cout, p, false);
+    dasv::wgrad_plan(B, H, W, Cin, Cout, q, true);
+    return (size_t)(p.S > q.S ? p.S : q.S) * Cout * 9 * Cin * sizeof(float);
 }
+
+static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                        void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 
 int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw, void* workspace, size_t workspace_bytes,
                             int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mode != 0 && mode != 1) return DASV_E_DTYPE;
+    return wgrad_launch(mode, x, nullptr, g, nullptr, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
+}
+
+int dasv_conv3x3_wgrad_x8_nhwc(const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                               void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (x_range == nullptr || g_range == nullptr) return DASV_E_NULL;     // the operands are scaled from their range records
+    return wgrad_launch(3, x, x_range, g, g_range, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
+}
+
+static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                        void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (x == nullptr || g == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return DASV_E_SHAPE;
     if ((long long)B * (H + 1) * (W + 1) > 0x7fffffffLL / 4) return DASV_E_SHAPE;
     // operands are addressed through 32-bit buffer offsets
     if ((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= 0xffffffffLL) return DASV_E_SHAPE;
-    if (mode != 0 && mode != 1) return DASV_E_DTYPE;
     dasv::WgradParams p;
-    dasv::wgrad_plan(B, H, W, Cin, Cout, p);
+    dasv::wgrad_plan(B, H, W, Cin, Cout, p, mode == 3);
     if (workspace_bytes < (size_t)p.S * Cout * 9 * Cin * sizeof(float)) return DASV_E_WORKSPACE;
     p.x = x; p.g = g; p.part = static_cast<float*>(workspace);
+    p.x_rec = x_range; p.g_rec = g_range;
     // two buffers; both planes are always carved (the bf16 mode simply leaves the lo planes unused)
     if (W > 80) return DASV_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(DASV_WGRAD_XCD ? ((p.ctiles * p.ntiles * p.S + 7) / 8) * 8 : p.ctiles * p.ntiles * p.S)), block(512);
     const int nx = (p.xrows + 15) / 16;
-#define DASV_LAUNCH_WGRAD(SP, NXV, PT)                                                                                 \
+#define DASV_LAUNCH_WGRAD(SP, NXV, PT, ...)                                                                            \
     do {                                                                                                           \
         const size_t lds = 2 * dasv::wgrad_buffer_bytes(NXV);                                                      \
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_wgrad_kernel<SP, NXV, PT>), \
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_wgrad_kernel<SP, NXV, PT __VA_OPT__(,) __VA_ARGS__>), \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
         if (e2 != hipSuccess) return (int)e2;                                                                      \
-        hipLaunchKernelGGL((dasv::conv3x3_wgrad_kernel<SP, NXV, PT>), grid, block, lds, s, p);                      \
+        hipLaunchKernelGGL((dasv::conv3x3_wgrad_kernel<SP, NXV, PT __VA_OPT__(,) __VA_ARGS__>), grid, block, lds, s, p); \
     } while (0)
     if (nx > 15) return DASV_E_SHAPE;   // maps wider than 80 columns
-    if (mode == 0) {
-        if (p.patch) DASV_LAUNCH_WGRAD(true, 7, true);
-        else if (nx <= 8) DASV_LAUNCH_WGRAD(true, 8, false);
-        else if (nx <= 10) DASV_LAUNCH_WGRAD(true, 10, false);
-        else DASV_LAUNCH_WGRAD(true, 15, false);
+    if (mode == 3) {
+        if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1, true);
+        else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2, true);
+        else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2, true);
+        else if (nx <= 8) DASV_LAUNCH_WGRAD(false, 8, 0, true);
+        else if (nx <= 10) DASV_LAUNCH_WGRAD(false, 10, 0, true);
+        else DASV_LAUNCH_WGRAD(false, 15, 0, true);
+    } else if (mode == 0) {
+        if (p.patch == 1) DASV_LAUNCH_WGRAD(true, 7, 1);
+        else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(true, 7, 2);
+        else if (p.patch == 2) DASV_LAUNCH_WGRAD(true, 10, 2);
+        else if (nx <= 8) DASV_LAUNCH_WGRAD(true, 8, 0);
+        else if (nx <= 10) DASV_LAUNCH_WGRAD(true, 10, 0);
+        else DASV_LAUNCH_WGRAD(true, 15, 0);
     } else {
-        if (p.patch) DASV_LAUNCH_WGRAD(false, 7, true);
-        else if (nx <= 8) DASV_LAUNCH_WGRAD(false, 8, false);
-        else if (nx <= 10) DASV_LAUNCH_WGRAD(false, 10, false);
-        else DASV_LAUNCH_WGRAD(false, 15, false);
+        if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1);
+        else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2);
+        else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2);
+        else if (nx <= 8) DASV_LAUNCH_WGRAD(false, 8, 0);
+        else if (nx <= 10) DASV_LAUNCH_WGRAD(false, 10, 0);
+        else DASV_LAUNCH_WGRAD(false, 15, 0);
     }
 #undef DASV_LAUNCH_WGRAD
     hipError_t e = hipGetLastError();

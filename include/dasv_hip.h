@@ -215,6 +215,11 @@ int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const flo
 size_t dasv_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int dasv_conv3x3_wgrad_nhwc(int mode, const float* x, const float* g, float* gw, void* workspace, size_t workspace_bytes,
                             int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+/* The same in the fp16 + e4m3 form of the `split8` forward mode: fp16 x fp16 products on the fp16 MFMA, both cross terms of the
+ * fp16 residuals on one block-scaled e4m3 MFMA (64 matrix-pipe cycles per 16 x 16 x 64 instead of 96), operands scaled by powers
+ * of two from their range records (x_range, g_range: [0] = bits of max |v|, an upper bound is enough; both mandatory). */
+int dasv_conv3x3_wgrad_x8_nhwc(const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                               void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 
 /* conv3x3 with ONE input channel (+ bias + ReLU): x [B,H,W] fp32 -> y [B,H,W,Cout] NHWC fp32.  Replaces
  * `F.relu(self.conv11(x))` (CNNs.py:38 / 72); w is the torch weight [Cout,1,3,3].  Cout % 4 == 0, (Cout/4) | 256. */

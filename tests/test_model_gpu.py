@@ -421,6 +421,22 @@ def test_hip_conv3x3_wgrad_vs_fp64(cin, cout, H, W, B):
     assert float((gwb - ref).abs().max()) / scale < 2e-2
     gw2 = conv.conv3x3_wgrad(x, g, "split").cpu().double()
     assert torch.equal(gw, gw2)   # fixed-order reduction: bitwise reproducible
+    # the fp16 + e4m3 form (split8): fp32-grade at any operand scale (range records), records that only BOUND the maximum, and
+    # a gradient with the heavy tail real ones have
+    gw8 = conv.conv3x3_wgrad(x, g, "split8").cpu().double()
+    assert float((gw8 - ref).abs().max()) / scale < 2e-5, float((gw8 - ref).abs().max()) / scale
+    assert torch.equal(gw8, conv.conv3x3_wgrad(x, g, "split8").cpu().double())
+    for fx, fg in ((3e4, 1e-7), (2e-6, 5e5)):
+        gws = conv.conv3x3_wgrad(x * fx, g * fg, "split8").cpu().double() / (fx * fg)
+        assert float((gws - ref).abs().max()) / scale < 2e-5, (fx, fg)
+    loose = conv.conv3x3_wgrad(x, g, "split8", x_rec=conv.range_of(x * 7.0), g_rec=conv.range_of(g * 30.0)).cpu().double()
+    assert float((loose - ref).abs().max()) / scale < 2e-5
+    gt = g * (1.0 + 3999.0 * (torch.rand_like(g) < 1e-3))
+    w1 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(xd, w1, None, padding=1) * gt.double().cpu()).sum().backward()
+    gwt = conv.conv3x3_wgrad(x, gt, "split8").cpu().double()
+    # (a sum that a few outliers dominate does not average the cross terms' e4m3 rounding — 2^-15 of a product — down: bar 2^-14)
+    assert float((gwt - w1.grad).abs().max()) / float(w1.grad.abs().max()) < 6.2e-5
 
 
 def test_fused_first_block_matches_unfused_and_torch():
