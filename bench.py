@@ -430,6 +430,7 @@ def main():
                          "cross terms (split8, default: ~1e-5 of the output scale per layer) or split-bf16 operands (split: ~5e-6), "
                          "single-MFMA bf16 / fp16 operands, or PyTorch-ROCm/MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip roofline.power_probe (profiling runs: its 200 launches would mix into the kernel statistics)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for real runs; gloo only to rehearse the multi-rank path on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -654,7 +655,7 @@ def main():
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
                         "mfma_util_pmc_percent": mfma_util_pmc()}
-            if world == 1 and args.workload == "embed" and args.conv == "split8":
+            if world == 1 and args.workload == "embed" and args.conv == "split8" and not args.no_power_probe:
                 roofline["power_probe"] = conv_power_probe(dev, B)
         # companions (never the headline `value`): the same step with the other operand modes of the convolutions, each with its
         # measured embedding error against the CPU oracle's fp32 embeddings of the same batch

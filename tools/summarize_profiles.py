@@ -156,6 +156,20 @@ for run in ("embed", "train"):
             md.append("| `%s` | %d | %.1f %% | %.1f %% |\n" % (k, len(v), sum(v) / len(v), max(v)))
             util["%s:%s" % (run, k)] = round(sum(v) / len(v), 2)
 traffic["mfma_util_percent"] = util
+# the round's diagnostic logs, verbatim (tools/collect_profiles.sh): the steady-state training step's kernel mix, the power test
+# (random vs all-zero data), the two weight-gradient forms, and the split8 tile stamps with the in-kernel clock
+for name, title in (("train_step_mix.md", None), ("conv_power_test.log", "power test: the same split8 launches on random and on all-zero data (tools/_diag/conv_power_test.py)"),
+                    ("wgrad_x8_ab.log", "weight gradient: split-bf16 vs fp16 + e4m3 form (tools/_diag/wgrad_x8_ab.py)"),
+                    ("conv_stamps.log", "split8 tile stamps and in-kernel clock (tools/conv_stamps.py)")):
+    path = os.path.join(src, name)
+    if not os.path.exists(path):
+        continue
+    text = "".join(l for l in open(path) if "amdgpu.ids" not in l)
+    if title is None:
+        open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(text)
+        md.append("\n## steady-state training step\n\n" + text)
+    else:
+        md.append("\n## %s\n\n```\n%s```\n" % (title, text))
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("".join(md))
 print("".join(md))
