@@ -71,8 +71,13 @@ def _conv_ragged(x, conv, packed, mode, span, x_packed=False, y_packed=False, x_
     x_rec / y_rec (split8): range records of x and y (conv.new_ranges)."""
     lib = _lib.load()
     rows, W, cin = x.shape
-    cout = conv.out_channels
-    hi, lo = packed.get(conv.weight, mode, conv.bias)
+    # narrow kernel sizes run as their zero-padded form (conv.supported): x may carry more channels than the layer has inputs
+    # (zeros), y gets padded_channels(Cout) channels, the surplus identically zero
+    cout = _conv.padded_channels(conv.out_channels)
+    pad = (cin, cout) if (cin, cout) != (conv.in_channels, conv.out_channels) else None
+    hi, lo = packed.get(conv.weight, mode, conv.bias, pad)
+    bias = packed.bias if (pad is not None and conv.bias is not None) else conv.bias
+    bias_ptr = None if bias is None else bias.detach().data_ptr()
     y = torch.empty((rows, W, cout), dtype=torch.float32, device=x.device)
     nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(1, rows, W, cin, cout)
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
@@ -86,14 +91,14 @@ def _conv_ragged(x, conv, packed, mode, span, x_packed=False, y_packed=False, x_
         with torch.cuda.device(x.device):
             rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(
                 x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                None if conv.bias is None else conv.bias.detach().data_ptr(), y.data_ptr(), int(y_packed),
+                bias_ptr, y.data_ptr(), int(y_packed),
                 None if y_rec is None else y_rec.data_ptr(), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin,
                 cout, 1, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_x8_nhwc")
         return y
     with torch.cuda.device(x.device):
         rc = lib.dasv_conv3x3_bias_relu_ragged_nhwc(
-            _conv.MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
+            _conv.MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), bias_ptr,
             y.data_ptr(), span.data_ptr(), None if ws is None else ws.data_ptr(), nws, rows, W, cin, cout, 1,
             torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_bias_relu_ragged_nhwc")
@@ -214,16 +219,20 @@ def front_end_ragged(front, utterances, mode=None):
             first = name.endswith("1")
             if conv.in_channels == 1:
                 rows = x.shape[0]
-                h = torch.empty((rows, W, conv.out_channels), dtype=torch.float32, device=dev)
+                # (narrow kernel sizes: the first layer zero-padded to the 64-multiple the wide kernels read, CNNs._c1_padded)
+                w11, b11 = front._c1_padded() if hasattr(front, "_c1_padded") else (conv.weight, conv.bias)
+                w11 = w11.detach().contiguous()
+                c11out = w11.shape[0]
+                h = torch.empty((rows, W, c11out), dtype=torch.float32, device=dev)
                 rh = next(recs) if x8 else None
-                wp, bp = conv.weight.detach().contiguous().data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr()
+                wp, bp = w11.data_ptr(), None if b11 is None else b11.detach().data_ptr()
                 with torch.cuda.device(dev):
                     if chain:
                         rc = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(x.data_ptr(), rx.data_ptr(), wp, bp, h.data_ptr(), rh.data_ptr(),
-                                                                          span.data_ptr(), rows, W, conv.out_channels, 1, stream)
+                                                                          span.data_ptr(), rows, W, c11out, 1, stream)
                     else:
                         rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(x.data_ptr(), wp, bp, h.data_ptr(), None if rh is None else rh.data_ptr(),
-                                                                       span.data_ptr(), rows, W, conv.out_channels, 1, stream)
+                                                                       span.data_ptr(), rows, W, c11out, 1, stream)
                 _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
                 h_packed = chain
             elif chain:
@@ -236,9 +245,6 @@ def front_end_ragged(front, utterances, mode=None):
                 h = _conv_ragged(h, conv, packed, mode, span, x_packed=h_packed, y_packed=first, x_rec=rh, y_rec=ry)
                 h_packed, rh = first, ry
             else:
-                if not _conv.exact(conv.in_channels, conv.out_channels):
-                    raise RuntimeError("ragged front-end: layer %s (%d -> %d channels) is outside the HIP kernel's shapes"
-                                       % (name, conv.in_channels, conv.out_channels))
                 key = (name, dev.index)
                 packed = front._packed.get(key)
                 if packed is None:
@@ -257,8 +263,11 @@ def front_end_ragged(front, utterances, mode=None):
                     pools[blk - 1].data_ptr(), rows_in, rows_out, W, h.shape[2], stream)
         _lib.check(rc, "dasv_maxpool2x2_ceil_ragged_nhwc")
         h, W, h_packed, rh = y, Wo, pack_out, ry
-    # [rows, F', C] -> [rows, C*F'] with feature = c*F' + f (CNNs.py:49-50 / 88-89)
-    frames = h.permute(0, 2, 1).reshape(h.shape[0], h.shape[2] * h.shape[1])
+    # [rows, F', C] -> [rows, C*F'] with feature = c*F' + f (CNNs.py:49-50 / 88-89); a zero-padded last layer gives its real channels
+    c_last = getattr(front, "conv%d2" % front.n_blocks).out_channels
+    if h.shape[2] != c_last:
+        h = h[:, :, :c_last]
+    frames = h.permute(0, 2, 1).reshape(h.shape[0], c_last * h.shape[1])
     return frames, list(lens[-1])
 
 

@@ -365,3 +365,23 @@ def test_ragged_fp16_activation_chain_vs_oracle():
         ref = oracle.embedding_forward(utts[i].unsqueeze(0), sd, 4, 32)[0]
         cos = float(torch.nn.functional.cosine_similarity(emb[i], ref, dim=0))
         assert _rel(emb[i], ref) < 1e-3 and 1 - cos < 1e-4, (lens[i], _rel(emb[i], ref), cos)
+
+
+@pytest.mark.parametrize("ks,heads,mode", [(512, 32, "split8"), (48, 4, "split8"), (256, 16, "fp16")])
+def test_ragged_batches_with_narrow_kernel_sizes_vs_oracle(ks, heads, mode):
+    """The ragged (variable-length) pass takes any kernel_size like the dense one: narrow layers run zero-padded on the hand-written
+    kernels (ragged._conv_ragged).  Each utterance's embedding against oracle.embedding_forward at its own length."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.ragged import embed_ragged
+    torch.manual_seed(78)
+    net = SpeakerClassifier(_default_params(ks=ks, heads=heads, spk=40), torch.device(DEV)).to(DEV).eval()
+    net.front_end.conv_mode = mode
+    lens = [150, 33, 401, 17, 250]
+    utts = [torch.from_numpy(rnd(600 + i, n, 80)) for i, n in enumerate(lens)]
+    got = embed_ragged(net, [u.to(DEV) for u in utts]).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    bar = 1e-4 if mode == "split8" else 1e-3
+    for i, u in enumerate(utts):
+        ref = oracle.embedding_forward(u.unsqueeze(0), sd, 4, heads)[0]
+        assert _rel(got[i], ref) < bar, (ks, mode, lens[i], _rel(got[i], ref))
