@@ -167,6 +167,31 @@ class ConvTimer:
         return us / len(self.rec), fl / len(self.rec), fl / us / 1e6   # avg us, avg flops, TFLOP/s
 
 
+class WgradTimer:
+    """Events around every hand-written weight-gradient launch (kernel + its fixed-order reduction) inside the timed region, with
+    the algorithmic FLOPs of each (2*9*Cin*Cout*B*H*W, as the forward layer)."""
+
+    def __init__(self, convmod):
+        self.rec, self.modes = [], set()
+        self.active = False
+        inner = convmod.conv3x3_wgrad
+
+        def timed(x, g, mode="split", *a, **k):
+            if not self.active:
+                return inner(x, g, mode, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(torch.cuda.current_stream(x.device))
+            y = inner(x, g, mode, *a, **k)
+            e.record(torch.cuda.current_stream(x.device))
+            B, cin, H, W = x.shape
+            self.rec.append((s, e, 2.0 * 9 * cin * g.shape[1] * B * H * W))
+            self.modes.add(mode)
+            return y
+        convmod.conv3x3_wgrad = timed
+
+    summary = ConvTimer.summary
+
+
 def pooling_config2(poolings, lib, dev, launches=200, reps=5):
     """BASELINE config 2 (DoubleMHA pooling only, B=64 T=300 D=512 heads=8, fp32): the fused kernel through the
     allocation-free plan launcher, back to back on torch's current stream, rotating over 8 input buffers (315 MB > the
@@ -482,6 +507,7 @@ def main():
     rs = np.random.RandomState(1234 + rank)
     timer = PoolTimer(poolings)
     ctimer = ConvTimer(convmod)
+    wtimer = WgradTimer(convmod)
     compute_dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     config = {}
 
@@ -578,10 +604,10 @@ def main():
     # state the warm-up left.
     run_steps(0, args.warmup)
     timer.active = True
-    ctimer.active = True
+    ctimer.active = wtimer.active = True
     elapsed, region_ms, els = timed_regions(lambda first, count: run_steps(args.warmup + first, count), 0, args.steps, args.regions, dist, dev)
     timer.active = False
-    ctimer.active = False
+    ctimer.active = wtimer.active = False
     nstep_timed = args.steps * len(els)
 
     if rank == 0:
@@ -655,6 +681,21 @@ def main():
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
                         "mfma_util_pmc_percent": mfma_util_pmc()}
+            wsum = wtimer.summary()
+            if wsum is not None:
+                wus, wfl, wtfs = wsum
+                wmode = "split8" if "split8" in wtimer.modes else sorted(wtimer.modes)[0]
+                wmult = {"split": 3, "split8": 2}.get(wmode, 1)
+                roofline["weight_gradient"] = {
+                    "kernel": "dasv::conv3x3_wgrad_kernel + conv3x3_wgrad_reduce (%s operands)" % wmode, "bound": "mfma",
+                    "achieved": round(wtfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s", "frac": round(wtfs / MFMA_BF16_PEAK_TFS, 4),
+                    "avg_launch_us": round(wus, 2), "algorithmic_flops_per_launch": wfl,
+                    "launches_per_step": len(wtimer.rec) // max(1, nstep_timed),
+                    "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": wmult,
+                    "mfma_executed_frac": round(wtfs * wmult / MFMA_BF16_PEAK_TFS, 4),
+                    "note": "each 64 x 64 tile streams its g and x channels for every pixel: the launch moves Cout/64 x |x| + Cin/64 x |g| "
+                            "bytes through the L2 (3.1 GB for conv12) and is held by that and by its producers' conversion, not by the "
+                            "matrix pipe (DESIGN.md 4.4b)"}
             if world == 1 and args.workload == "embed" and args.conv == "split8" and not args.no_power_probe:
                 roofline["power_probe"] = conv_power_probe(dev, B)
         # companions (never the headline `value`): the same step with the other operand modes of the convolutions, each with its
