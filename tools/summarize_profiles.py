@@ -53,7 +53,13 @@ def bench_line(run):
     return None
 
 
+import subprocess
+try:
+    head = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h %s"], text=True).strip()
+except Exception:
+    head = "unknown"
 traffic, md = {}, ["# rocprofv3 summary, round tag `%s`\n\n" % tag,
+                   "Collected with the sources of commit `%s` (the last commit touching a kernel precedes it).\n\n" % head,
                    "Commands: `tools/collect_profiles.sh %s` (kernel-trace + stats pass, then separate `--pmc FETCH_SIZE` and "
                    "`--pmc WRITE_SIZE` passes) around `python3 bench.py --workload pool ...` and `python3 bench.py ...`.\n\n" % tag,
                    "FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B for wide coalesced reads, MI355X_MICROARCH.md "
