@@ -123,19 +123,31 @@ __device__ __forceinline__ hs_f4 load_agent4(const float* base, int byte_off, in
 template <bool VEC4>
 __device__ __forceinline__ void fold_publish(const FwdParams& p, int b, int a, const float* cbuf, const float* ubuf) {
     const int lane = threadIdx.x & 63, dh = p.dh, upw = p.upw, pitch = part_pitch(dh);
+    // at most 8 heads per workgroup (upw <= nw <= 8, the launch planner): their scores are read once, with the index clamped instead of a
+    // `k < upw` branch per read, the weights e^(u_k - M) computed once, and a feature's `upw` context values fetched together —
+    // written as loops over the runtime `upw` every read waited for the one before it (1.7 us from the unit's result to the
+    // published partial in the model's shape)
+    float uk[8], wk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) uk[k] = ubuf[k < upw ? k : 0];
     float M = -INFINITY;
-    for (int k = 0; k < upw; ++k) M = fmaxf(M, ubuf[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) M = fmaxf(M, k < upw ? uk[k] : -INFINITY);
     const float Mu = (M == -INFINITY) ? 0.f : M;
     float S = 0.f;
-    for (int k = 0; k < upw; ++k) S += fast_exp2((ubuf[k] - Mu) * kLog2e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { wk[k] = k < upw ? fast_exp2((uk[k] - Mu) * kLog2e) : 0.f; S += wk[k]; }
     float* pp = p.exch_p + ((size_t)b * p.nparts + a) * pitch;
     if (lane < upw) store_agent(p.exch_u + (size_t)b * round_up_i(p.H, 4) + a * upw + lane, ubuf[lane]);
     if constexpr (VEC4) {
         if (lane == 0) store_agent4(pp, 0, pitch * 4, hs_f4{M, S, 0.f, 0.f});
         for (int q = lane; q < (dh >> 2); q += 64) {
+            hs_f4 cv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[k] = *reinterpret_cast<const hs_f4*>(cbuf + (size_t)(k < upw ? k : 0) * dh + q * 4);
             hs_f4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < upw; ++k)
-                v += fast_exp2((ubuf[k] - Mu) * kLog2e) * *reinterpret_cast<const hs_f4*>(cbuf + (size_t)k * dh + q * 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += wk[k] * cv[k];
             store_agent4(pp, (4 + q * 4) * 4, pitch * 4, v);
         }
     } else {
@@ -421,15 +433,35 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
         }
     }
     __syncthreads();
+    DASV_STAMP(p, 7);
 
     // (5) finish the unit: (M, L) by every thread (<= 8 independent LDS reads); context vector + head score by
     //     the unit's first wave (P independent LDS reads per feature)
+    // (The waves-per-unit count is a launch parameter, and written as `k < wpu` tests inside unrolled loops this section compiled
+    // into a chain of scalar branches with ONE LDS read — and its wait — per branch: 0.96 us from the barrier to the unit's result in
+    // BASELINE config 2, 1.32 us in the model's shape (tools/stamps_dmha.py).  The reads carry no dependence: one straight-line
+    // copy per wpu in {1, 2, 4, 8} issues them all before anything waits.)
     const float* uml = red_ml + (size_t)uu * wpu * 2;
     float mwv[8], lwv[8];
+    auto read_ml = [&](auto wpu_c) {
+        constexpr int WPU = decltype(wpu_c)::value;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        mwv[k] = (k < wpu) ? uml[2 * k] : -INFINITY;
-        lwv[k] = (k < wpu) ? uml[2 * k + 1] : 0.f;
+        for (int k = 0; k < 8; ++k) {
+            mwv[k] = (k < WPU) ? uml[2 * k] : -INFINITY;
+            lwv[k] = (k < WPU) ? uml[2 * k + 1] : 0.f;
+        }
+    };
+    switch (wpu) {
+        case 1: read_ml(std::integral_constant<int, 1>{}); break;
+        case 2: read_ml(std::integral_constant<int, 2>{}); break;
+        case 4: read_ml(std::integral_constant<int, 4>{}); break;
+        case 8: read_ml(std::integral_constant<int, 8>{}); break;
+        default:
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                mwv[k] = (k < wpu) ? uml[2 * k] : -INFINITY;
+                lwv[k] = (k < wpu) ? uml[2 * k + 1] : 0.f;
+            }
     }
     float M = -INFINITY;
 #pragma unroll
@@ -452,14 +484,33 @@ __global__ void __launch_bounds__(512) dmha_fwd_vec(const FwdParams p) {
             const int d = lane + 64 * kd;
             if (d < DH) {
                 float v = 0.f;
+                auto sum_groups = [&](auto wpu_c) {
+                    constexpr int WPU = decltype(wpu_c)::value;
+                    float sg[WPU];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k < wpu) {
-                        float sg = 0.f;
+                    for (int k = 0; k < WPU; ++k) {
+                        sg[k] = 0.f;
 #pragma unroll
-                        for (int g2 = 0; g2 < GPW; ++g2) sg += ua[(size_t)(k * GPW + g2) * DH + d];
-                        v = fmaf(sg, fw[k], v);
+                        for (int g2 = 0; g2 < GPW; ++g2) sg[k] += ua[(size_t)(k * GPW + g2) * DH + d];
                     }
+#pragma unroll
+                    for (int k = 0; k < WPU; ++k) v = fmaf(sg[k], fw[k], v);
+                };
+                switch (wpu) {
+                    case 1: sum_groups(std::integral_constant<int, 1>{}); break;
+                    case 2: sum_groups(std::integral_constant<int, 2>{}); break;
+                    case 4: sum_groups(std::integral_constant<int, 4>{}); break;
+                    case 8: sum_groups(std::integral_constant<int, 8>{}); break;
+                    default:
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if (k < wpu) {
+                                float sg = 0.f;
+#pragma unroll
+                                for (int g2 = 0; g2 < GPW; ++g2) sg += ua[(size_t)(k * GPW + g2) * DH + d];
+                                v = fmaf(sg, fw[k], v);
+                            }
+                        }
                 }
                 const float cv = v * invL;
                 if (cg != nullptr) cg[d] = cv;               // a plain output: nothing in this launch reads it back

@@ -91,7 +91,8 @@ def main():
         s = s[used]
         wmax = wv.max(axis=1)
         wmin = np.where(wv > 0, wv, np.inf).min(axis=1)
-        skew.append((np.median(wmax - wmin) * 0.01, np.median(wmax - s[:, 2]) * 0.01, np.median(s[:, 3] - wmax) * 0.01))
+        skew.append((np.median(wmax - wmin) * 0.01, np.median(wmax - s[:, 2]) * 0.01, np.median(s[:, 3] - wmax) * 0.01,
+                     np.median(s[:, 7] - wmax) * 0.01, np.median(s[:, 3] - s[:, 7]) * 0.01))
         t0 = s[:, 0].min()
         rows = []
         for k in range(7):
@@ -116,7 +117,8 @@ def main():
         n = agg[0, k, 3]
         print("%-18s %8.2f %8.2f %8.2f %6d" % (nm, np.median(agg[:, k, 0]), np.median(agg[:, k, 1]), np.median(agg[:, k, 2]), 0 if np.isnan(n) else int(n)))
     sk = np.median(np.array(skew), axis=0)
-    print("per-wave loop-done: median spread within a workgroup %.2f us; slowest wave after wave 0: %.2f us; slowest wave -> unit done: %.2f us" % tuple(sk))
+    print("per-wave loop-done: median spread within a workgroup %.2f us; slowest wave after wave 0: %.2f us; slowest wave -> unit done: %.2f us "
+          "(of which slowest wave -> partials parked + barrier %.2f, barrier -> unit done %.2f)" % tuple(sk))
     ivals = np.array(ivals, dtype=np.float64)
     print("per-workgroup intervals (us): p10 / median / p90 / max / n")
     for k in range(6):
