@@ -247,7 +247,9 @@ class _VGG(nn.Module):
                                                           "split" if self._mode() == "split8" else self._mode())   # no fused form of split8
             elif grad:
                 rh = next(recs) if x8 else None
-                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, *self._c1_padded(), rh)
+                # conv12 runs with mask_input_grad (below) whenever it is on the HIP kernel: conv11's ReLU mask is then applied there
+                h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, *self._c1_padded(), rh,
+                                                           grad_premasked=self._use_hip_conv("conv12", paddedInputTensor))
             else:
                 rh = next(recs) if x8 else None
                 w11, b11 = self._c1_padded()

@@ -562,9 +562,10 @@ class _Conv11ReLUFn(torch.autograd.Function):
     """relu(conv2d(x[:,None], w, b, padding 1)) for x [B,H,W] (no gradient w.r.t. x: x is the input feature map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, y_rec):
+    def forward(ctx, x, weight, bias, y_rec, grad_premasked=False):
         y = conv3x3_c1_bias_relu(x, weight, bias, y_rec=y_rec)
         ctx.save_for_backward(x.contiguous(), y)
+        ctx.grad_premasked = grad_premasked
         ctx.has_bias = bias is not None
         ctx.wshape = weight.shape
         return y
@@ -581,13 +582,16 @@ class _Conv11ReLUFn(torch.autograd.Function):
         nbytes = lib.dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, cout)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            rc = lib.dasv_conv3x3_c1_bwd_nhwc(x.data_ptr(), y.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+            # (grad_premasked: the consumer's data-gradient kernel multiplied gy by (y > 0) already — y is not read again)
+            rc = lib.dasv_conv3x3_c1_bwd_nhwc(x.data_ptr(), None if ctx.grad_premasked else y.data_ptr(), gy.data_ptr(), gw.data_ptr(),
                                               None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes, B, H, W, cout,
                                               torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_c1_bwd_nhwc")
-        return None, gw, gb, None
+        return None, gw, gb, None, None
 
 
-def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None):
-    """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad."""
-    return _Conv11ReLUFn.apply(x, weight, bias, y_rec)
+def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None, grad_premasked=False):
+    """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad.
+    grad_premasked: the one consumer of the result applies this layer's ReLU mask to the gradient it sends back (a following
+    conv3x3_bias_relu(..., mask_input_grad=True)), so the backward reads that gradient only."""
+    return _Conv11ReLUFn.apply(x, weight, bias, y_rec, grad_premasked)

@@ -294,10 +294,12 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __rest
     if (pl < ppb) {
         for (long long pix = p0 + pl; pix < p1; pix += ppb) {
             const int w_ = (int)(pix % W), h_ = (int)((pix / W) % H);
-            const f4 yy = *reinterpret_cast<const f4*>(y + (size_t)pix * Cout + q * 4);
             f4 g = *reinterpret_cast<const f4*>(gy + (size_t)pix * Cout + q * 4);
+            if (y != nullptr) {      // (null: the producer of gy applied this layer's ReLU mask already — half the traffic)
+                const f4 yy = *reinterpret_cast<const f4*>(y + (size_t)pix * Cout + q * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) g[c] = yy[c] > 0.f ? g[c] : 0.f;
+                for (int c = 0; c < 4; ++c) g[c] = yy[c] > 0.f ? g[c] : 0.f;
+            }
             float in[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -496,7 +498,7 @@ size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {
 
 int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream) {
-    if (x == nullptr || y == nullptr || gy == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;
+    if (x == nullptr || gy == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;      // y may be NULL: gy pre-masked
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     if (workspace_bytes < dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, Cout)) return DASV_E_WORKSPACE;
     const long long npix = (long long)B * H * W;

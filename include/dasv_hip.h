@@ -272,7 +272,9 @@ int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* g
 int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C);
 /* Backward of the one-input-channel layer: from x [B,H,W], its output y [B,H,W,Cout] and gy (gradient w.r.t. y, before
  * the ReLU mask): gw [Cout,1,3,3] and gb [Cout] (or NULL), both OVERWRITTEN; fixed-order reduction.  Replaces autograd's
- * backward of `F.relu(self.conv11(x))` (CNNs.py:38 / 72).  workspace: dasv_conv3x3_c1_bwd_workspace_bytes(). */
+ * backward of `F.relu(self.conv11(x))` (CNNs.py:38 / 72).  workspace: dasv_conv3x3_c1_bwd_workspace_bytes().
+ * y == NULL: gy already carries the mask (the data-gradient kernel of the layer above applied it, dasv_conv3x3_masked_*): the
+ * launch then reads gy only. */
 size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout);
 int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream);

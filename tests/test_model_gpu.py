@@ -500,7 +500,7 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
     torch.manual_seed(5)
     net = VGG4L(ks).to(DEV).train()
     x = torch.from_numpy(rnd(61, 2, 45, 80)).to(DEV)
-    orig_conv, orig_pool = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd
+    orig_conv, orig_pool, orig_c1 = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd, C.conv3x3_c1_bias_relu_autograd
     cap = {}
 
     def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, link_in=None, link_out=None, x_rec=None,
@@ -518,6 +518,9 @@ def test_frontend_training_backward_hip_equals_torch(ks, monkeypatch):
         monkeypatch.setattr(C, "conv3x3_bias_relu", lambda *a, fuse=fuse, **k: capturing(*a, fuse=fuse, **k))
         monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, x_rec=None, y_rec=None, fuse=fuse:
                             orig_pool(t, relu_input and fuse, link_out if fuse else None, x_rec, y_rec))
+        # (conv11 leaves its ReLU mask to conv12's data-gradient kernel in the fused wiring only)
+        monkeypatch.setattr(C, "conv3x3_c1_bias_relu_autograd", lambda t, w, b, y_rec=None, grad_premasked=False, fuse=fuse:
+                            orig_c1(t, w, b, y_rec, grad_premasked and fuse))
         net.conv_mode = "torch" if mode == "torch" else "split"
         net.zero_grad()
         cap.clear()
