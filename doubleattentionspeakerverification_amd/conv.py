@@ -512,37 +512,46 @@ def conv3x3_c1_conv3x3_bias_relu(mel, w1, b1, weight2, bias2, packed=None, mode=
 
 
 class _MaxPoolFn(torch.autograd.Function):
-    """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward (arg-max recomputed)."""
+    """2x2 stride-2 ceil-mode max-pool on channels_last fp32 with a hand-written backward.  The forward launch also writes one
+    byte per pooled element {arg-max position | 4 if the maximum is > 0} (dasv_maxpool2x2_ceil_idx_nhwc); the backward reads those
+    bytes and the incoming gradient only — the full-resolution map is not saved and not read again."""
 
     @staticmethod
     def forward(ctx, x, relu_input, link_out, x_rec, y_rec):
+        lib = _lib.load()
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
-        y = maxpool2x2_ceil(x, x_rec=x_rec, y_rec=y_rec)
-        ctx.save_for_backward(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_maxpool2x2_ceil_idx_nhwc(x.data_ptr(), None if x_rec is None else x_rec.data_ptr(), y.data_ptr(),
+                                                   None if (x_rec is None or y_rec is None) else y_rec.data_ptr(), idx.data_ptr(),
+                                                   B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_idx_nhwc")
+        ctx.save_for_backward(idx)
+        ctx.xshape = (B, C, H, W)
         ctx.relu_input = relu_input
         ctx.link_out = link_out
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
+        (idx,) = ctx.saved_tensors
         lib = _lib.load()
-        B, C, H, W = x.shape
+        B, C, H, W = ctx.xshape
         gy = gy.contiguous(memory_format=torch.channels_last)
-        gx = torch.empty_like(x, memory_format=torch.channels_last)
-        with torch.cuda.device(x.device):
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            if ctx.relu_input:
-                rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if ctx.link_out is not None else 0
-                part = torch.empty((rows, C), dtype=torch.float32, device=x.device) if rows > 0 else None
-                rc = lib.dasv_maxpool2x2_ceil_relu_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(),
-                                                            None if part is None else part.data_ptr(), B, H, W, C, stream)
-                if part is not None and rc == 0:
-                    ctx.link_out["gb"] = part.sum(dim=0)
-            else:
-                rc = lib.dasv_maxpool2x2_ceil_bwd_nhwc(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, stream)
-        _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_nhwc")
+        gx = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(gy.device):
+            stream = torch.cuda.current_stream(gy.device).cuda_stream
+            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if (ctx.relu_input and ctx.link_out is not None) else 0
+            part = torch.empty((rows, C), dtype=torch.float32, device=gy.device) if rows > 0 else None
+            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), gx.data_ptr(), None if part is None else part.data_ptr(),
+                                                       int(bool(ctx.relu_input)), B, H, W, C, stream)
+            if part is not None and rc == 0:
+                ctx.link_out["gb"] = part.sum(dim=0)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
         rec = getattr(gy, "_dasv_rec", None)
         if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)
             gx._dasv_rec = rec

@@ -153,7 +153,10 @@ __global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restri
 __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int H, int W, int C, int Ho, int Wo, long long nvec,
                                                               const int* __restrict__ pool_src, int pack,
-                                                              const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec, int in_f16) {
+                                                              const uint32_t* __restrict__ x_rec, uint32_t* __restrict__ y_rec, int in_f16,
+                                                              uint8_t* __restrict__ idx) {
+    // idx (optional, fp32 input only): [outputs][C] bytes {arg-max position 0-3 | 4 if the maximum is > 0} for the backward pass
+    // (training): it then needs neither x nor a second look at the window
     // in_f16: x is a half-precision tensor holding v * 2^Ex (fp16 activation chain).  pack 2: y is one too, with the SAME exponent
     // (the maximum commutes with a positive scale: the halves are compared and copied, nothing is rounded); pack 0 with in_f16:
     // fp32 out, unscaled.
@@ -205,9 +208,26 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
             for (int c = 0; c < 4; ++c) a[c] = (v[c] > a[c] || v[c] != v[c]) ? v[c] : a[c];
             return a;
         };
-        if (hw) m = mx(m, *reinterpret_cast<const f4*>(base + C));
-        if (hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C));
-        if (hw && hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C + C));
+        if (idx != nullptr) {
+            // row-major scan, strict '>' — the first maximum wins, as ATen's kernel does (and a NaN takes over)
+            int arg[4] = {0, 0, 0, 0};
+            auto mxa = [&](f4 v, int pos) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (v[c] > m[c] || v[c] != v[c]) { m[c] = v[c]; arg[c] = pos; }
+            };
+            if (hw) mxa(*reinterpret_cast<const f4*>(base + C), 1);
+            if (hh) mxa(*reinterpret_cast<const f4*>(base + (size_t)W * C), 2);
+            if (hw && hh) mxa(*reinterpret_cast<const f4*>(base + (size_t)W * C + C), 3);
+            uint32_t code = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) code |= (uint32_t)(arg[c] | (m[c] > 0.f ? 4 : 0)) << (8 * c);
+            *reinterpret_cast<uint32_t*>(idx + (size_t)op * C + q * 4) = code;
+        } else {
+            if (hw) m = mx(m, *reinterpret_cast<const f4*>(base + C));
+            if (hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C));
+            if (hw && hh) m = mx(m, *reinterpret_cast<const f4*>(base + (size_t)W * C + C));
+        }
         if (pack) store_x8(y, op, C, q * 4, m, sy);
         else *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m;
     }
@@ -218,7 +238,9 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
 // all of the window's input gradients: gy to the arg-max, zero elsewhere.  No indices tensor, no atomics, no memset.
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
-                                                                  long long nvec, int relu_mask, float* __restrict__ colsum) {
+                                                                  long long nvec, int relu_mask, float* __restrict__ colsum,
+                                                                  const uint8_t* __restrict__ idx) {
+    // idx (optional): the forward pass's {arg-max | 4 if maximum > 0} bytes — x is then not read (x may be null)
     // colsum (optional): [gridDim.x][C] per-channel sums of the gradient this workgroup scattered (= the bias gradient of
     // the conv whose ReLU output was pooled).  Needs (C/4) | 256 so that a thread keeps the same four channels throughout.
     __shared__ f4 red[256];
@@ -233,10 +255,19 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         const size_t base = (((size_t)b * H + h0) * W + w0) * C + q * 4;
         const bool hw = w0 + 1 < W, hh = h0 + 1 < H;
         const size_t o1 = base + C, o2 = base + (size_t)W * C, o3 = o2 + C;
-        const f4 v0 = *reinterpret_cast<const f4*>(x + base);
         f4 g = *reinterpret_cast<const f4*>(gy + (size_t)op * C + q * 4);
-        f4 m = v0;
         int arg[4] = {0, 0, 0, 0};
+        f4 m = {1.f, 1.f, 1.f, 1.f};
+        if (idx != nullptr) {
+            const uint32_t code = *reinterpret_cast<const uint32_t*>(idx + (size_t)op * C + q * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                arg[c] = (int)((code >> (8 * c)) & 3u);
+                m[c] = ((code >> (8 * c)) & 4u) ? 1.f : 0.f;
+            }
+        } else {
+        const f4 v0 = *reinterpret_cast<const f4*>(x + base);
+        m = v0;
         f4 v1, v2, v3;
         if (hw) { v1 = *reinterpret_cast<const f4*>(x + o1);
 #pragma unroll
@@ -247,6 +278,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         if (hw && hh) { v3 = *reinterpret_cast<const f4*>(x + o3);
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (v3[c] > m[c] || v3[c] != v3[c]) { m[c] = v3[c]; arg[c] = 3; } }
+        }
         f4 r0, r1, r2, r3;
         if (relu_mask) {   // x is a ReLU's output: pass the gradient through that ReLU too (zero where the maximum is not > 0)
 #pragma unroll
@@ -396,8 +428,9 @@ int dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(const float* x, const uint32_t* x_r
 }
 
 static int pool_launch(const float* x, float* y, const int* pool_src, int B, int H, int Ho, int W, int C, int pack,
-                       const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream, int in_f16 = 0) {
+                       const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream, int in_f16 = 0, uint8_t* idx = nullptr) {
     if (x == nullptr || y == nullptr) return DASV_E_NULL;
+    if (idx != nullptr && in_f16) return DASV_E_DTYPE;
     if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;
     if (in_f16 && (x_range == nullptr || pack == 1)) return in_f16 && x_range == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (pack == 2 && !in_f16) return DASV_E_SHAPE;
@@ -407,7 +440,7 @@ static int pool_launch(const float* x, float* y, const int* pool_src, int B, int
     long long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dasv::maxpool2x2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo,
-                       nvec, pool_src, pack, x_range, y_range, in_f16);
+                       nvec, pool_src, pack, x_range, y_range, in_f16, idx);
     return (int)hipGetLastError();
 }
 
@@ -465,15 +498,15 @@ static long long maxpool_bwd_blocks(int B, int H, int W, int C) {
 }
 
 static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
-                              float* colsum, dasv_stream_t stream) {
+                              float* colsum, dasv_stream_t stream, const uint8_t* idx = nullptr) {
     if (colsum != nullptr && (C / 4 > 256 || 256 % (C / 4) != 0)) return DASV_E_SHAPE;
-    if (x == nullptr || gy == nullptr || gx == nullptr) return DASV_E_NULL;
+    if ((x == nullptr && idx == nullptr) || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
     const long long blocks = maxpool_bwd_blocks(B, H, W, C);
     hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
-                       C, Ho, Wo, nvec, relu_mask, colsum);
+                       C, Ho, Wo, nvec, relu_mask, colsum, idx);
     return (int)hipGetLastError();
 }
 
@@ -484,6 +517,20 @@ int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, in
 int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, float* colsum_partial, int B, int H, int W,
                                        int C, dasv_stream_t stream) {
     return maxpool_bwd_launch(x, gy, gx, B, H, W, C, 1, colsum_partial, stream);
+}
+
+/* training: the forward pool also writes one byte per pooled element {arg-max position 0-3 | 4 if the maximum is > 0}; the backward
+ * pass then reads those bytes and gy only — not the full-resolution map (786 MB for the first block of a [64,300,80] batch) */
+int dasv_maxpool2x2_ceil_idx_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, uint8_t* idx, int B, int H,
+                                  int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr) return DASV_E_NULL;
+    return pool_launch(x, y, nullptr, B, H, (H + 1) / 2, W, C, 0, x_range, y_range, stream, 0, idx);
+}
+
+int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask, int B,
+                                      int H, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr) return DASV_E_NULL;
+    return maxpool_bwd_launch(nullptr, gy, gx, B, H, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx);
 }
 
 int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C) {

@@ -267,6 +267,14 @@ int dasv_maxpool2x2_ceil_bwd_nhwc(const float* x, const float* gy, float* gx, in
  * ReLU (zero where the window maximum is not > 0), which saves the separate mask pass over [B,H,W,C]. */
 int dasv_maxpool2x2_ceil_relu_bwd_nhwc(const float* x, const float* gy, float* gx, float* colsum_partial, int B, int H, int W,
                                        int C, dasv_stream_t stream);
+/* Training form of the pool: the forward launch also writes `idx` [B,Ho,Wo,C] bytes {arg-max position 0-3 (row-major in the window,
+ * the first maximum wins as in ATen) | 4 if the maximum is > 0}, and the backward launch reads those bytes and gy only — not the
+ * full-resolution input again.  relu_mask != 0: the pooled map was a ReLU's output, the gradient passes that ReLU too (the bit);
+ * colsum_partial as in dasv_maxpool2x2_ceil_relu_bwd_nhwc (or NULL).  Results identical to the index-free pair. */
+int dasv_maxpool2x2_ceil_idx_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, uint8_t* idx, int B, int H,
+                                  int W, int C, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask, int B,
+                                      int H, int W, int C, dasv_stream_t stream);
 /* rows of the optional colsum_partial [rows][C] above (per-workgroup channel sums of gx = that conv's bias gradient after a
  * sum over the first axis); 0 when C does not allow it ((C/4) must divide 256). */
 int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C);
