@@ -407,6 +407,10 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
         const char* Glo = Ghi + WKC * 128;
         const char* Xhi = Glo + WKC * 128;
         const int* Ltab = reinterpret_cast<const int*>(Xhi + 2 * xplane);
+        if constexpr (X8 && DASV_WGRAD_DIAG == 2) { __syncthreads(); continue; }     // timing build: producers alone
+        // (Measured, tools/wgrad_diag.py with WGRAD_X8=1, seven layers: full 5.46 ms, consumers alone 4.00 ms — against 2.5 ms of
+        // matrix-pipe time — producers alone 2.98 ms.  Fragments requested two taps ahead instead of one: consumers alone 0.70 ->
+        // 0.71 ms on the patch layers (they are not waiting for LDS round trips) and 25 spilled registers in the whole-row variant.)
         if constexpr (X8) {
             typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
             typedef int i32x8 __attribute__((ext_vector_type(8)));

@@ -41,8 +41,14 @@ def time_round_robin(gos, rounds=3, reps=4):
     return best
 
 
+X8 = os.environ.get("WGRAD_X8") == "1"
+
+
 def run():
     import torch
+    sys.path.insert(0, ROOT)
+    global hc
+    from doubleattentionspeakerverification_amd import conv as hc
     dev = torch.device("cuda:0")
     layers = [("conv12", 128, 128, 300, 80), ("conv21", 128, 256, 150, 40), ("conv22", 256, 256, 150, 40),
               ("conv31", 256, 512, 75, 20), ("conv32", 512, 512, 75, 20), ("conv41", 512, 1024, 38, 10), ("conv42", 1024, 1024, 38, 10)]
@@ -53,6 +59,8 @@ def run():
         lib.dasv_conv3x3_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 5
         lib.dasv_conv3x3_wgrad_nhwc.restype = ctypes.c_int
         lib.dasv_conv3x3_wgrad_nhwc.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        lib.dasv_conv3x3_wgrad_x8_nhwc.restype = ctypes.c_int
+        lib.dasv_conv3x3_wgrad_x8_nhwc.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
         libs[n] = lib
     B = 64
     tot = {n: 0.0 for n in NAMES}
@@ -60,6 +68,7 @@ def run():
         x = torch.relu(torch.randn(B, cin, H, W, device=dev)).contiguous(memory_format=torch.channels_last)
         g = torch.randn(B, cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         gw = torch.empty(cout, cin, 3, 3, device=dev)
+        xr, gr = hc.range_of(x), hc.range_of(g)
         line = "%s %4d->%4d %3dx%2d |" % (name, cin, cout, H, W)
         gos = {}
         for n, lib in libs.items():
@@ -68,7 +77,11 @@ def run():
             st = torch.cuda.current_stream().cuda_stream
 
             def go(lib=lib, ws=ws, nb=nb):
-                rc = lib.dasv_conv3x3_wgrad_nhwc(0, x.data_ptr(), g.data_ptr(), gw.data_ptr(), ws.data_ptr(), nb, B, H, W, cin, cout, st)
+                if X8:      # WGRAD_X8=1 in the environment: the fp16 + e4m3 form
+                    rc = lib.dasv_conv3x3_wgrad_x8_nhwc(x.data_ptr(), xr.data_ptr(), g.data_ptr(), gr.data_ptr(), gw.data_ptr(), ws.data_ptr(), nb,
+                                                        B, H, W, cin, cout, st)
+                else:
+                    rc = lib.dasv_conv3x3_wgrad_nhwc(0, x.data_ptr(), g.data_ptr(), gw.data_ptr(), ws.data_ptr(), nb, B, H, W, cin, cout, st)
                 assert rc == 0, rc
             gos[n] = go
         best = time_round_robin(gos)
