@@ -404,9 +404,115 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __rest
     else if (gb != nullptr) gb[n] = v;
 }
 
+// Border tables of a ragged batch (ragged.py), made on the device from the utterance lengths alone: blockIdx.y = table
+// (2 l: spans of level l — {first row, one past the last row} of the utterance owning each row; 2 l + 1: the pool closing level l —
+// {first input row, has-second-row} per output row; 2 levels: {owner, row inside the utterance} of every output frame, int64 for
+// torch indexing).  Every workgroup rebuilds the (tiny) per-utterance prefix sums of its level in LDS and finds a row's owner by
+// binary search.  One launch replaces ~60 cumsum / repeat_interleave / arange / gather launches per group of utterances.
+struct RaggedTablesParams {
+    int B, levels;
+    int off[17];      // int32 offset of table k in `out` (k < 2 * levels)
+    int rows[9];      // rows at level l (rows[levels] = output frames)
+};
+constexpr int kRaggedMaxB = 4096;
+
+__global__ void __launch_bounds__(256) ragged_tables_kernel(const int* __restrict__ lens, const RaggedTablesParams p, int* __restrict__ out,
+                                                            long long* __restrict__ fin) {
+    __shared__ int len_a[kRaggedMaxB], st_a[kRaggedMaxB + 1], st_b[kRaggedMaxB + 1], part[256];
+    const int k = blockIdx.y, tid = threadIdx.x, B = p.B;
+    const bool final_tab = k == 2 * p.levels;
+    const int l = final_tab ? p.levels : k >> 1;
+    const bool pool = !final_tab && (k & 1);
+    const int nrows = pool ? p.rows[l + 1] : p.rows[l];
+    if ((long long)blockIdx.x * 256 >= nrows) return;
+    // lengths at level l (len_a) and, for a pool table, at level l + 1; exclusive prefix sums st_a (level l) / st_b (level l + 1)
+    const int E = (B + 255) / 256;
+    auto scan = [&](int shift, int* st) {
+        int acc = 0;
+        for (int e = 0; e < E; ++e) {
+            const int b = tid * E + e;
+            if (b < B) {
+                int n = lens[b];
+                for (int q = 0; q < shift; ++q) n = (n + 1) >> 1;
+                if (st == st_a) len_a[b] = n;
+                acc += n;
+            }
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; }
+        }
+        __syncthreads();
+        int run = part[tid];
+        for (int e = 0; e < E; ++e) {
+            const int b = tid * E + e;
+            if (b < B) {
+                int n = lens[b];
+                for (int q = 0; q < shift; ++q) n = (n + 1) >> 1;
+                st[b] = run;
+                run += n;
+            }
+        }
+        if (tid == 255) st[B] = run;      // (threads past the last utterance carry the total)
+        __syncthreads();
+    };
+    scan(l, st_a);
+    if (pool) scan(l + 1, st_b);
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= nrows) return;
+    const int* st = pool ? st_b : st_a;
+    int lo = 0, hi = B - 1;               // largest b with st[b] <= r
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (st[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    if (final_tab) {
+        fin[r] = lo;
+        fin[(size_t)nrows + r] = r - st_a[lo];
+    } else if (!pool) {
+        out[p.off[k] + 2 * r] = st_a[lo];
+        out[p.off[k] + 2 * r + 1] = st_a[lo] + len_a[lo];
+    } else {
+        const int local = r - st_b[lo];
+        out[p.off[k] + 2 * r] = st_a[lo] + 2 * local;
+        out[p.off[k] + 2 * r + 1] = (2 * local + 1 < len_a[lo]) ? 1 : 0;
+    }
+}
+
 }  // namespace dasv
 
 extern "C" {
+
+int dasv_ragged_tables(const int* lengths_dev, const int* lengths_host, int B, int levels, int* tables, long long* frame_index,
+                       dasv_stream_t stream) {
+    if (lengths_dev == nullptr || lengths_host == nullptr || tables == nullptr) return DASV_E_NULL;
+    if (B <= 0 || B > dasv::kRaggedMaxB || levels <= 0 || levels > 8) return DASV_E_SHAPE;
+    dasv::RaggedTablesParams p;
+    p.B = B; p.levels = levels;
+    long long off = 0;
+    for (int l = 0; l <= levels; ++l) {
+        long long rows = 0;
+        for (int b = 0; b < B; ++b) {
+            int n = lengths_host[b];
+            if (n <= 0) return DASV_E_SHAPE;
+            for (int q = 0; q < l; ++q) n = (n + 1) >> 1;
+            rows += n;
+        }
+        if (rows > 0x3fffffff) return DASV_E_SHAPE;
+        p.rows[l] = (int)rows;
+    }
+    for (int l = 0; l < levels; ++l) {
+        p.off[2 * l] = (int)off;     off += 2LL * p.rows[l];
+        p.off[2 * l + 1] = (int)off; off += 2LL * p.rows[l + 1];
+        if (off > 0x7fffffff) return DASV_E_SHAPE;
+    }
+    const dim3 grid((unsigned)((p.rows[0] + 255) / 256), (unsigned)(2 * levels + (frame_index != nullptr ? 1 : 0)));
+    hipLaunchKernelGGL(dasv::ragged_tables_kernel, grid, dim3(256), 0, (hipStream_t)stream, lengths_dev, p, tables, frame_index);
+    return (int)hipGetLastError();
+}
+
 
 static int c1_launch(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cout, int relu,
                      const int* row_span, dasv_stream_t stream, int pack, const uint32_t* x_range, uint32_t* y_range) {

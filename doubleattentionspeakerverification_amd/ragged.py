@@ -32,36 +32,72 @@ def _upload_int64(values, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
-def ragged_tables(lengths, levels, device):
+def _upload_np(arr, device):
+    """A small numpy array as a device tensor without blocking the host (pinned staging, see _upload_int64)."""
+    t = torch.from_numpy(arr)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def ragged_tables(lengths, levels, device, with_index=False):
     """Border tables for `levels` conv blocks.  Returns (spans, pools, lens): spans[l] int32 [rows_l, 2] (first row, one
     past the last row of the owning utterance) for the maps entering block l; pools[l] int32 [rows_{l+1}, 2] (first input
     row, has-second-row) of the pool that closes block l; lens[l] the utterance lengths at level l as a Python list
-    (lens[levels] = output lengths)."""
-    spans, pools, lens = [], [], []
-    cur_host = [int(n) for n in lengths]
-    if not cur_host or min(cur_host) <= 0:
+    (lens[levels] = output lengths).  with_index: a fourth value, int64 [2, rows_levels] = (owner utterance, row inside it) of
+    every output frame.
+
+    On the GPU the tables come from ONE launch (dasv_ragged_tables) fed by one tiny non-blocking upload of the lengths.  Round 2
+    built them with torch ops — ~60 tiny launches per group (cumsum / repeat_interleave / arange / gather / stack per level),
+    11 % of the GPU time of a variable-length step; building them on the host and uploading ~400 KB per group instead made the
+    HOST the bottleneck (132 -> 240-330 ms per step: copies of that size do not run ahead of the stream the way tiny ones do)."""
+    import numpy as np
+    cur = np.asarray([int(n) for n in lengths], dtype=np.int64)
+    if cur.size == 0 or cur.min() <= 0:
         raise ValueError("lengths must be a non-empty list of positive frame counts")
-    # one tiny host->device copy (the lengths); everything else is computed on the device with known output sizes, so
-    # there is no synchronisation and no large pageable copy (those cost milliseconds each)
-    cur = _upload_int64(cur_host, device)
-    ids = torch.arange(len(cur_host), device=device)
+    device = torch.device(device)
+    lens, rows = [], []
+    c = cur
+    for _ in range(levels + 1):
+        lens.append([int(n) for n in c])
+        rows.append(int(c.sum()))
+        c = (c + 1) // 2
+    if device.type == "cuda":
+        lib = _lib.load()
+        host = np.ascontiguousarray(cur, dtype=np.int32)
+        dev_lens = _upload_np(host, device)
+        total = sum(2 * (rows[l] + rows[l + 1]) for l in range(levels))
+        flat = torch.empty(total, dtype=torch.int32, device=device)
+        fin = torch.empty((2, rows[levels]), dtype=torch.int64, device=device) if with_index else None
+        with torch.cuda.device(device):
+            rc = lib.dasv_ragged_tables(dev_lens.data_ptr(), host.ctypes.data, int(cur.size), levels, flat.data_ptr(),
+                                        None if fin is None else fin.data_ptr(), torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(rc, "dasv_ragged_tables")
+        spans, pools, off = [], [], 0
+        for l in range(levels):
+            spans.append(flat[off:off + 2 * rows[l]].view(rows[l], 2))
+            off += 2 * rows[l]
+            pools.append(flat[off:off + 2 * rows[l + 1]].view(rows[l + 1], 2))
+            off += 2 * rows[l + 1]
+        return (spans, pools, lens, fin) if with_index else (spans, pools, lens)
+    # host arithmetic (CPU tensors: the tests' reference walk, and the specification of the kernel above)
+    spans, pools = [], []
+    c = cur
     for _ in range(levels):
-        lens.append(cur_host)
-        rows = sum(cur_host)
-        start = torch.cumsum(cur, 0) - cur
-        owner = torch.repeat_interleave(ids, cur, output_size=rows)
-        spans.append(torch.stack([start[owner], (start + cur)[owner]], dim=1).to(torch.int32))
-        nxt_host = [(n + 1) // 2 for n in cur_host]
-        nxt = (cur + 1) // 2
-        orows = sum(nxt_host)
-        ostart = torch.cumsum(nxt, 0) - nxt
-        oowner = torch.repeat_interleave(ids, nxt, output_size=orows)
-        local = torch.arange(orows, device=device) - ostart[oowner]       # output row inside its utterance
-        first = start[oowner] + 2 * local
-        second = (2 * local + 1 < cur[oowner]).to(torch.int64)
-        pools.append(torch.stack([first, second], dim=1).to(torch.int32))
-        cur, cur_host = nxt, nxt_host
-    lens.append(cur_host)
+        start = np.cumsum(c) - c
+        span = np.stack([np.repeat(start, c), np.repeat(start + c, c)], axis=1)
+        nxt = (c + 1) // 2
+        ostart = np.cumsum(nxt) - nxt
+        local = np.arange(int(nxt.sum()), dtype=np.int64) - np.repeat(ostart, nxt)          # output row inside its utterance
+        first = np.repeat(start, nxt) + 2 * local
+        second = (2 * local + 1 < np.repeat(c, nxt)).astype(np.int64)
+        spans.append(torch.from_numpy(span.astype(np.int32)).to(device))
+        pools.append(torch.from_numpy(np.stack([first, second], axis=1).astype(np.int32)).to(device))
+        c = nxt
+    if with_index:
+        fin = torch.from_numpy(np.stack([np.repeat(np.arange(c.size, dtype=np.int64), c),
+                                         np.arange(int(c.sum()), dtype=np.int64) - np.repeat(np.cumsum(c) - c, c)])).to(device)
+        return spans, pools, lens, fin
     return spans, pools, lens
 
 
@@ -182,9 +218,14 @@ def _front_end_ragged_f16(front, x, spans, pools, lens, dev):
 
 
 @torch.no_grad()
-def front_end_ragged(front, utterances, mode=None):
+def front_end_ragged(front, utterances, mode=None, with_index=False):
     """VGG front-end over stacked utterances.  Returns (frames [sum T'_i, D] with the reference's feature order c*F'+f,
-    lengths T'_i as a list)."""
+    lengths T'_i as a list); with_index: also int64 [2, sum T'_i] = (owner utterance, row inside it) of every frame."""
+    out = _front_end_ragged(front, utterances, mode)
+    return out if with_index else out[:2]
+
+
+def _front_end_ragged(front, utterances, mode):
     lib = _lib.load()
     dev = next(front.parameters()).device
     if dev.type != "cuda":
@@ -194,7 +235,7 @@ def front_end_ragged(front, utterances, mode=None):
         raise RuntimeError("the ragged path needs the HIP convolutions (conv_mode split8 / split / bf16 / fp16)")
     x = torch.cat([u.to(dev, torch.float32) for u in utterances], dim=0).contiguous()        # [rows, 80]
     W = x.shape[1]
-    spans, pools, lens = ragged_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev)
+    spans, pools, lens, fin = ragged_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev, with_index=True)
     stream = torch.cuda.current_stream(dev).cuda_stream
     # split8: the activations between the layers in the consumer's operand form, as in CNNs._forward_map_packed — when no launch
     # of the chain wants split-K (groups of utterances that fill the chip; a packed output has no split-K form)
@@ -202,7 +243,7 @@ def front_end_ragged(front, utterances, mode=None):
     if mode == "fp16" and getattr(front, "half_activations", False) and _packed_chain_ok(front, x.shape[0], W, pools):
         # the fp16-operand mode with HALF-PRECISION activation tensors between the layers (CNNs._forward_map_f16; BASELINE
         # config 5 names exactly this: variable-length batches on the fp16 MFMA path)
-        return _front_end_ragged_f16(front, x, spans, pools, lens, dev)
+        return _front_end_ragged_f16(front, x, spans, pools, lens, dev) + (fin,)
     h, h_packed = None, False
     # split8: one range record per tensor of the pass (conv.new_ranges; CNNs._forward_map_packed)
     x8 = mode == "split8"
@@ -268,7 +309,7 @@ def front_end_ragged(front, utterances, mode=None):
     if h.shape[2] != c_last:
         h = h[:, :, :c_last]
     frames = h.permute(0, 2, 1).reshape(h.shape[0], c_last * h.shape[1])
-    return frames, list(lens[-1])
+    return frames, list(lens[-1]), fin
 
 
 @torch.no_grad()
@@ -276,15 +317,12 @@ def embed_ragged(net, utterances, mode=None):
     """Embeddings [len(utterances), emb] of utterances with arbitrary (different) frame counts, one set of launches."""
     if net.training:
         raise RuntimeError("embed_ragged is an inference path: call net.eval() first")
-    frames, tl = front_end_ragged(net.front_end, utterances, mode)
+    import numpy as np
+    frames, tl, fin = front_end_ragged(net.front_end, utterances, mode, with_index=True)
     B, tmax, D = len(tl), max(tl), frames.shape[1]
     padded = frames.new_zeros((B, tmax, D))
-    lens64 = _upload_int64(tl, frames.device)
-    owner = torch.repeat_interleave(torch.arange(B, device=frames.device), lens64, output_size=frames.shape[0])
-    start = torch.cumsum(lens64, 0) - lens64
-    local = torch.arange(frames.shape[0], device=frames.device) - start[owner]
-    padded[owner, local] = frames
-    lengths = lens64.to(torch.int32)
+    padded[fin[0], fin[1]] = frames          # (owner, row) of every frame: made with the border tables (ragged_tables)
+    lengths = _upload_np(np.asarray(tl, dtype=np.int32), frames.device)
     pool = net.poolingLayer
     if isinstance(pool, _pool.DoubleMHA):
         vec = pool.pool(padded, lengths=lengths)

@@ -275,6 +275,15 @@ int dasv_maxpool2x2_ceil_idx_nhwc(const float* x, const uint32_t* x_range, float
                                   int W, int C, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask, int B,
                                       int H, int W, int C, dasv_stream_t stream);
+/* Border tables of a ragged batch (utterances of different lengths stacked along time: what the reference does one utterance per
+ * forward, train.py:117-133), made on the device in ONE launch from the B utterance lengths (lengths_dev int32 on the device;
+ * lengths_host the same values on the host: the sizes below are host arithmetic).  rows_l = sum_b ceil(len_b / 2^l).
+ * tables (int32, 2 * sum_{l < levels} (rows_l + rows_{l+1}) entries), level by level:
+ *   spans_l [rows_l][2]    = {first row, one past the last row} of the utterance that owns the row (row_span of the `_ragged` entries)
+ *   pools_l [rows_{l+1}][2] = {first input row, 1 if the 2x2 window has a second row} per pooled row (pool_src)
+ * frame_index (optional, int64 [2][rows_levels]): {owner utterance, row inside it} of every output frame.  B <= 4096, levels <= 8. */
+int dasv_ragged_tables(const int* lengths_dev, const int* lengths_host, int B, int levels, int* tables, long long* frame_index,
+                       dasv_stream_t stream);
 /* rows of the optional colsum_partial [rows][C] above (per-workgroup channel sums of gx = that conv's bias gradient after a
  * sum over the first axis); 0 when C does not allow it ((C/4) must divide 256). */
 int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C);

@@ -1044,3 +1044,15 @@ def test_amsoftmax_hip_head_default_size_vs_float64():
         assert float((res[fused][2].double() - xd.grad).abs().max()) <= 2e-5 * float(xd.grad.abs().max())
         assert float((res[fused][3].double() - Wd.grad).abs().max()) <= 2e-5 * float(Wd.grad.abs().max())
     assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-5 * float(res[False][2].abs().max())
+
+
+@pytest.mark.parametrize("lens,levels", [([1], 4), ([17, 1, 800, 2, 3], 4), ([5] * 300 + [799, 1, 2], 3), ([301, 150, 299], 1)])
+def test_ragged_tables_kernel_equals_the_host_walk(lens, levels):
+    """dasv_ragged_tables (one launch per group of utterances) against the host arithmetic that specifies it (ragged.ragged_tables on
+    CPU tensors, itself checked against a naive walk in tests/test_host_cpu.py): spans, pools and the frame index, bit for bit."""
+    from doubleattentionspeakerverification_amd.ragged import ragged_tables
+    sd, pd, ld, fd = ragged_tables(lens, levels, torch.device(DEV), with_index=True)
+    sh, ph, lh, fh = ragged_tables(lens, levels, "cpu", with_index=True)
+    assert ld == lh
+    for a, b in zip(sd + pd + [fd], sh + ph + [fh]):
+        assert a.dtype == b.dtype and torch.equal(a.cpu(), b)
