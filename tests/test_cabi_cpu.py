@@ -97,6 +97,16 @@ def test_split_k_plan_and_the_packed_chain_gate(lib_path):
     assert lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(None, 1, None, None, None, None, None, 0, None, None, None, 0, 100, 40, 128, 256, 1, None) < 0
     assert lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(None, None, None, None, None, None, None, 100, 80, 128, 1, None) < 0
     assert lib.dasv_maxpool2x2_ceil_ragged_x8_nhwc(None, None, None, None, None, 100, 50, 80, 128, None) < 0
+    # round-3 entry points refuse missing tables / records / index bytes before touching the device
+    assert lib.dasv_conv3x3_wgrad_x8_nhwc(16, None, 16, 16, 16, 16, 1 << 30, 2, 8, 8, 64, 64, None) == -1
+    assert lib.dasv_conv3x3_wgrad_x8_nhwc(16, 16, 16, None, 16, 16, 1 << 30, 2, 8, 8, 64, 64, None) == -1
+    assert lib.dasv_maxpool2x2_ceil_idx_nhwc(16, None, 16, None, None, 2, 8, 8, 64, None) == -1
+    assert lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(None, 16, 16, None, 1, 2, 8, 8, 64, None) == -1
+    assert lib.dasv_ragged_tables(None, None, 3, 4, None, None, None) == -1
+    import ctypes
+    three = (ctypes.c_int * 3)(5, 0, 7)
+    assert lib.dasv_ragged_tables(16, ctypes.addressof(three), 3, 4, 16, None, None) == -2      # a zero-length utterance
+    assert lib.dasv_ragged_tables(16, ctypes.addressof(three), 5000, 4, 16, None, None) == -2   # more utterances than a group may hold
     # the half-precision ragged chain: tables and records are mandatory
     assert lib.dasv_conv3x3_bias_relu_ragged_f16_nhwc(16, 1, 16, 16, None, 16, 1, 16, None, None, 0, 100, 40, 128, 256, 1, None) == -1
     assert lib.dasv_conv3x3_c1_bias_relu_ragged_f16_nhwc(16, 16, 16, None, 16, 16, None, 100, 80, 128, 1, None) == -1
