@@ -482,6 +482,18 @@ def test_hip_maxpool_and_conv11_backward_match_torch():
     (yr * gy).sum().backward()
     np.testing.assert_allclose(g1[0].cpu().numpy(), w.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()))
     np.testing.assert_allclose(g1[1].cpu().numpy(), b.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()))
+    # a gradient that already carries the layer's ReLU mask (what conv12's masked data-gradient kernel sends back): the launch
+    # that skips reading y must give the same sums bit for bit (odd sizes: partial last trips of its four-pixel loop)
+    for shp in ((3, 41, 80), (2, 7, 5), (1, 300, 80)):
+        xx = torch.from_numpy(rnd(77, *shp)).to(DEV)
+        gg = torch.from_numpy(rnd(78, shp[0], 128, shp[1], shp[2])).to(DEV)
+        res = []
+        for pre in (False, True):
+            w.grad = b.grad = None
+            yy = conv.conv3x3_c1_bias_relu_autograd(xx, w, b, None, pre)
+            yy.backward(gg * (yy.detach() > 0) if pre else gg)
+            res.append((w.grad.clone(), b.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), shp
 
 
 @pytest.mark.parametrize("ks", [1024, 512])
