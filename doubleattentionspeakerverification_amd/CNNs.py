@@ -153,6 +153,7 @@ class _VGG(nn.Module):
         epilogue only because it goes through LDS (coalescing epilogue): with 8- and 4-byte stores straight to memory the packed
         output cost the producing layer 18 % (tools/_diag/packed_pieces.py)."""
         dev = x.device
+        x = x.contiguous()      # (a time crop `feats[:, s:s+T]` is a view: the record below must be taken over what conv11 reads)
         # one range record per tensor of the chain (conv.new_ranges): the input features' is measured (6 MB), every kernel fills
         # its output's; a packed tensor is scaled by the exponent its producer left in its record
         recs = _hipconv.new_ranges(dev, 1 + 3 * self.n_blocks)
@@ -182,6 +183,7 @@ class _VGG(nn.Module):
         f16 -> pool -> f16 -> ... -> convN2 -> f16 -> last pool -> fp32 map.  Every tensor holds v * 2^E, E from its range record
         (conv.conv3x3_f16); values are rounded to fp16 once per layer — the rounding the fp16 operands apply anyway."""
         dev = x.device
+        x = x.contiguous()      # (see _forward_map_packed)
         recs = _hipconv.new_ranges(dev, 1 + 3 * self.n_blocks)
         r = iter(recs)
         rx = next(r)

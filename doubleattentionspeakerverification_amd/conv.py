@@ -144,6 +144,22 @@ def invalidate_packed_weights(module):
                     pk.invalidate()
 
 
+def _attach_rec(t, rec):
+    """Let the range record of a gradient tensor ride on it to the kernel that consumes it (the layer below's data / weight
+    gradient), together with the tensor's version counter: autograd accumulates a second consumer's gradient IN PLACE into the
+    same tensor object, which keeps the attribute but bumps the version — the record is then stale and `_rec_of`
+    re-measures."""
+    t._dasv_rec = (rec, t._version)
+
+
+def _rec_of(t):
+    """The record attached by `_attach_rec` if the tensor has not been written since, else None (the caller measures)."""
+    tagged = getattr(t, "_dasv_rec", None)
+    if tagged is None or tagged[1] != t._version:
+        return None
+    return tagged[0]
+
+
 def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None):
     """colsum (with mask): a dict that receives 'gb' = per-channel sums of the masked output (fixed-order partial sums
     from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel.
@@ -259,7 +275,7 @@ class _ConvReLUFn(torch.autograd.Function):
         dmode = DGRAD_MODE[ctx.mode] if x.shape[3] <= 80 else bmode       # (the split8 form exists in the window kernel only)
         # split8 data gradient: the incoming gradient's range record rides on the tensor when a kernel of this library produced it
         # (the layer above's data gradient, the pool's backward); otherwise one pass over it measures it
-        g_rec = getattr(gy, "_dasv_rec", None) if dmode == "split8" else None
+        g_rec = _rec_of(gy) if dmode == "split8" else None
         gx_rec = new_ranges(x.device)[0] if dmode == "split8" else None
         want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
@@ -281,7 +297,7 @@ class _ConvReLUFn(torch.autograd.Function):
                 gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
                              colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec)
                 if gx_rec is not None:
-                    gx._dasv_rec = gx_rec
+                    _attach_rec(gx, gx_rec)
             else:
                 gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec)[:, :cin_x].contiguous(memory_format=torch.channels_last)
                 if ctx.mask_input_grad:
@@ -292,7 +308,7 @@ class _ConvReLUFn(torch.autograd.Function):
             wmode = WGRAD_MODE[ctx.mode]
             # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
             gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
-                               g_rec=getattr(gy, "_dasv_rec", None) if wmode == "split8" else None)
+                               g_rec=_rec_of(gy) if wmode == "split8" else None)
             if padded:
                 gw = gw[:cout, :cin].contiguous()
             want_w = False
@@ -552,9 +568,9 @@ class _MaxPoolFn(torch.autograd.Function):
             if part is not None and rc == 0:
                 ctx.link_out["gb"] = part.sum(dim=0)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
-        rec = getattr(gy, "_dasv_rec", None)
+        rec = _rec_of(gy)
         if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)
-            gx._dasv_rec = rec
+            _attach_rec(gx, rec)
         return gx, None, None, None, None
 
 

@@ -144,7 +144,11 @@ __global__ void __launch_bounds__(256) amsoftmax_fwd_kernel(const AmParams p) {
 }
 
 // lse_b from the column-tile partials (fixed order), loss = mean_b (lse_b - logit_b,label)
+// A label outside [0, N) has no column: nothing wrote lab_logit[b].  The reference raises there (scatter_ at loss.py:47,
+// CrossEntropyLoss at train.py:219); a launch cannot raise, so the loss becomes NaN — loudly wrong instead of a finite value made
+// of uninitialised workspace.
 __global__ void __launch_bounds__(256) amsoftmax_ce_finish_kernel(const float* __restrict__ part, const float* __restrict__ lab_logit,
+                                                                  const long long* __restrict__ label, int N,
                                                                   float* __restrict__ lse, float* __restrict__ loss, int B, int ntile) {
     __shared__ float red[256];
     float local = 0.f;
@@ -155,7 +159,8 @@ __global__ void __launch_bounds__(256) amsoftmax_ce_finish_kernel(const float* _
         for (int t = 0; t < ntile; ++t) se += part[((long long)b * ntile + t) * 2 + 1] * __expf(part[((long long)b * ntile + t) * 2] - mx);
         const float l = mx + __logf(se);
         lse[b] = l;
-        local += l - lab_logit[b];
+        const long long lab = label[b];
+        local += l - ((lab >= 0 && lab < (long long)N) ? lab_logit[b] : __builtin_nanf(""));
     }
     red[threadIdx.x] = local;
     __syncthreads();
@@ -370,7 +375,7 @@ int dasv_amsoftmax_fwd(const float* x, const float* W, const int64_t* label, flo
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (loss != nullptr) {
-        hipLaunchKernelGGL(dasv::amsoftmax_ce_finish_kernel, dim3(1), dim3(256), 0, s, p.part, p.lab_logit, lse, loss, B, ntile);
+        hipLaunchKernelGGL(dasv::amsoftmax_ce_finish_kernel, dim3(1), dim3(256), 0, s, p.part, p.lab_logit, p.label, N, lse, loss, B, ntile);
         e = hipGetLastError();
     }
     return (int)e;

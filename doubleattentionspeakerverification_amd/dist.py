@@ -165,7 +165,9 @@ class FlatGradReducer:
         self._cold_bufs.append(buf)
 
     def finish(self):
-        """After backward: reduce buckets whose hooks never all fired, wait, average."""
+        """After backward: reduce buckets whose hooks never all fired, wait.  The buffers then hold the SUM over the ranks: the
+        caller scales its loss by `grad_scale` (= 1 / world) before backward — DataParallelTrainer does — so that no extra pass
+        over the 86 MB buffer is needed to turn the sum into the global-batch mean (train.py:219: CrossEntropyLoss is a mean)."""
         self._in_finish = True
         try:
             for bi in range(len(self.buckets)):
@@ -179,17 +181,28 @@ class FlatGradReducer:
         if cold:
             for buf in self._cold_bufs:
                 self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        was_armed, self._armed = self._armed, False
+        if self.world > 1 and was_armed:
+            # Which parameters fired is agreed over the ranks (MAX) before anything is decided from it: what is retired to the cold
+            # buffers (a rank-local decision could leave the ranks with different numbers of cold buffers, i.e. different collective
+            # sequences: a hang) and what hide_unused() hides from the optimizer (a parameter hidden on one rank and updated on
+            # another: diverging weights) — ADVICE r3.  One tiny collective and one host read per optimizer step.
+            flags = torch.tensor([self._fired, self._fired_armed], dtype=torch.int32).to(self.flat.device)
+            self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
         self._works = []
-        was_armed, self._armed = self._armed, False
-        if self.world > 1:
-            self.flat.mul_(1.0 / self.world)
-            if cold:
-                for buf in self._cold_bufs:
-                    buf.mul_(1.0 / self.world)
+        if self.world > 1 and was_armed:
+            fl = flags.cpu().tolist()
+            self._fired = [bool(v) for v in fl[0]]
+            self._fired_armed = [bool(v) for v in fl[1]]
         if was_armed:      # finish() without arm() saw no backward: nothing may be retired on its evidence
             self._retire_unfired()
+
+    @property
+    def grad_scale(self):
+        """What the caller multiplies its (mean) loss by so that the summed buffers hold the global-batch mean's gradient."""
+        return 1.0 / self.world
 
     def zero(self):
         self.flat.zero_()
@@ -237,9 +250,21 @@ class DataParallelTrainer:
         self.fused_loss = True     # use net.forward_loss (fused AM-softmax + CE head) when the model has one
         self._micro = 0
 
+    def sync_buffers(self):
+        """Rank 0's BUFFERS (BatchNorm running statistics) to every rank.  Policy across ranks: the reference's nn.DataParallel
+        keeps the statistics of the replica on GPU 0 — the replicas' buffer updates are dropped at the end of every forward
+        (train.py:68-70) — i.e. those of the first shard of every batch.  Here every rank updates its own module
+        from its own shard, so rank 0's module holds exactly what the reference's would: checkpoints are written by rank 0 from
+        its own state (utils.py:23-40) and need nothing else; ranks > 0 call this before they evaluate (validation, scoring), or
+        their drifted statistics would be used.  Training itself never reads the running statistics (b2 normalises with batch
+        statistics in train mode, model.py:57)."""
+        if self.world > 1:
+            with torch.no_grad():
+                for t in self.net.buffers():
+                    dist.broadcast(t, src=0, group=self.group)
+
     def broadcast_state(self):
-        """Rank 0's parameters and buffers to everyone (initialisation, and what DataParallel's
-        keep-GPU-0's-BatchNorm-statistics behaviour amounts to at checkpoint time)."""
+        """Rank 0's parameters and buffers to everyone (initialisation)."""
         from .conv import invalidate_packed_weights
         with torch.no_grad():   # in place on the tensors themselves, so their version counters move
             for t in list(self.net.parameters()) + list(self.net.buffers()):
@@ -263,7 +288,10 @@ class DataParallelTrainer:
                 costh, logits = self.net(x, label=labels, step=step)
         if fused is None:
             loss = self.criterion(logits.float(), labels)
-        loss.backward()
+        # the all-reduce SUMS over the ranks: 1 / world goes into the loss (exact for 2, 4, 8 ranks) instead of a pass over the
+        # flat gradient buffer afterwards; every micro-batch of an accumulation is scaled, they are summed into the same buffer
+        scale = self.reducer.grad_scale
+        (loss if scale == 1.0 else loss * scale).backward()
         if last:
             self.reducer.finish()
             hidden = self.reducer.hide_unused()

@@ -374,6 +374,9 @@ int dasv_dmha_bwd_nhwc_f32(const float* x, const float* query, const float* att,
  * Backward: gx [B,E], gW [E,N] (OVERWRITTEN) from either the fused loss (lse given; g_loss [1] = upstream gradient of the loss
  * or NULL for 1) or upstream gradients of the two module outputs (lse NULL; g_costh / g_logits [B,N], either may be NULL).
  * Deterministic (fixed-order reductions).  workspace: dasv_amsoftmax_workspace_bytes(), no init needed.
+ * Labels must lie in [0, N): the reference raises on anything else (scatter_, loss.py:47; CrossEntropyLoss, train.py:219); a launch
+ * cannot, so an out-of-range label makes the fused loss NaN (the row has no target column) — check labels on the host if a finite
+ * loss must mean valid labels; costh / logits of such a row are the margin-free values.
  * ------------------------------------------------------------------------ */
 size_t dasv_amsoftmax_workspace_bytes(int B, int E, int N);
 int dasv_amsoftmax_fwd(const float* x, const float* W, const int64_t* label, float* costh, float* logits, float* loss, float* lse,

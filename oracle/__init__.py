@@ -13,3 +13,4 @@ reference (imported read-only from /root/reference in the build container by
 ``tests/golden/``).
 """
 from .dmha_oracle import *  # noqa: F401,F403
+from .train_oracle import *  # noqa: F401,F403

@@ -146,7 +146,7 @@ class LateBloomer(TinyClassifier):
         return z, 3.0 * z
 
 
-def _worker_steps(rank, world, port, out_dir):
+def _worker_steps(rank, world, port, out_dir, lopsided=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from doubleattentionspeakerverification_amd.dist import DataParallelTrainer, init_distributed, shard_batch
     init_distributed("gloo")
@@ -158,7 +158,8 @@ def _worker_steps(rank, world, port, out_dir):
     lo, hi = shard_batch(x.size(1), rank, world)
     from_hook = []
     for step in range(3):
-        net.use_extra = step >= 1
+        # lopsided: from step 1 on the late layer fires on rank 0 ONLY (a data-dependent graph)
+        net.use_extra = step >= 1 and (rank == 0 or not lopsided)
         tr.train_step(x[step % 2, lo:hi], y[step % 2, lo:hi], step=step)
         from_hook.append(list(tr.reducer.launched_from_hook))
     cold = sorted(tr.reducer._cold)
@@ -194,6 +195,21 @@ def test_unused_parameters_do_not_hold_back_buckets_and_late_gradients_are_reduc
     assert set(r0["cold"]) == {"unused.weight", "unused.bias", "bn.weight", "bn.bias", "extra.weight", "extra.bias"}
     assert not all(r0["from_hook"][0])          # first step: some bucket waited for the parameters that never fire
     assert all(r0["from_hook"][1]) and all(r0["from_hook"][2])
+
+
+def test_a_gradient_that_fires_on_one_rank_only_keeps_the_ranks_in_step(tmp_path):
+    """which parameters fired is agreed over the ranks before anything is retired to the cold buffers or hidden from the
+    optimizer.  A layer that (from step 1 on) takes part in the graph on rank 0 only must neither change the sequence of
+    collectives (a hang) nor be updated on one rank and skipped on the other (diverging weights): both ranks apply the reduced
+    gradient — rank 0's contribution over the two ranks."""
+    port = _free_port()
+    mp.spawn(_worker_steps, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert float((r0["state"]["extra.weight"] - LateBloomerInit.extra_weight()).abs().max()) > 0   # it did train, on both
+    assert r0["cold"] == r1["cold"]
 
 
 class LateBloomerInit:

@@ -211,3 +211,39 @@ def test_c_restatement_masked_heads(c_oracle):
         f = c_oracle(g["c%d_x" % i], g["c%d_query" % i], g["c%d_att" % i], g["c%d_keep" % i])
         np.testing.assert_allclose(f["out"], g["c%d_out" % i], atol=2e-6)
         np.testing.assert_allclose(f["align"], g["c%d_align" % i], atol=1e-6)
+
+
+# ------------------------------------------------------------------ G7 (the training-step restatement, oracle/train_oracle.py)
+def g7_batches(g, tag, num_spkrs=11):
+    """The two micro-batches of fixture G7 (tests/golden/make_golden.py g7): inputs, labels, the explicit head masks."""
+    out = []
+    for mb in range(2):
+        x = torch.from_numpy(rnd(1300 + mb, 4, 40, 80))
+        lab = torch.tensor([(3 * mb + j) % num_spkrs for j in range(4)])
+        out.append((x, lab, torch.from_numpy(g[tag + "_keep"][mb])))
+    return out
+
+
+@pytest.mark.parametrize("tag", ["adam", "sgd"])
+def test_g7_train_step_gradients(tag):
+    """train.py:215-226 restated in float64 under its own ReLU / max-pool decisions: the reference's two losses and every
+    gradient tensor of fixture G7 (the reference ran fp32: 1-D gradients behind train-mode BatchNorm are rounding residue of
+    cancelling terms there — absolute bound, as in tests/test_model_gpu.py)."""
+    g = load_golden("g7_train_step")
+    sd = sd_from_golden(g, tag + "_init_")
+    losses, grads, used = oracle.train_step_grads(sd, g7_batches(g, tag), 4, 0.4, 30.0)
+    np.testing.assert_allclose(losses, g[tag + "_losses"], rtol=2e-6)
+    assert sorted(set(k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k) - set(grads)) == \
+        sorted(str(n) for n in g[tag + "_nograd"])
+    for n, gr in grads.items():
+        ref = g[tag + "_grad_" + n.replace(".", "__")]
+        atol = 2e-3 if ref.ndim == 1 else 2e-5 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(gr.numpy(), ref, rtol=2e-3, atol=atol, err_msg=n)
+    # a forward that takes the SAME decisions has no flips; one perturbed pre-activation sign is counted
+    rec = {}
+    p64 = {k: v.double() for k, v in sd.items()}
+    oracle.vgg_forward_decided(g7_batches(g, tag)[0][0].double(), p64, 4, None, rec)
+    assert sum(oracle.count_flips(rec, rec, 4).values()) == 0
+    other = {k: v.clone() for k, v in rec.items()}
+    other["conv21"][0, 0, 0, 0] ^= True
+    assert oracle.count_flips(rec, other, 4)["conv21"] == 1
