@@ -28,7 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--shape", default="64,300,512,8")
-    ap.add_argument("--tuning", default="0,0,0,0", help="nw,wpu,ldspad,rows")
+    ap.add_argument("--tuning", default="0,0,0,0,0", help="nw,wpu,ldspad,rows,force_generic")
+    ap.add_argument("--nhwc", action="store_true", help="the front-end's NHWC map [B,T,5,C] pooled in place (D = 5 C)")
     ap.add_argument("--no-att", action="store_true")
     ap.add_argument("--no-align", action="store_true")
     ap.add_argument("--nbuf", type=int, default=8)
@@ -54,17 +55,25 @@ def main():
     out, hw = torch.empty(B, dh, device=dev), torch.empty(B, H, device=dev)
     align = torch.empty(B, T, H, device=dev)
     ctx, ml = torch.empty(B, H, dh, device=dev), torch.empty(B, H, 2, device=dev)
-    ws = torch.zeros(1 << 24, dtype=torch.uint8, device=dev)
+    ws = torch.zeros(1 << 26, dtype=torch.uint8, device=dev)
     nwg_max = 8 * ((B + 7) // 8) * H
     stamps = torch.zeros(2 * nwg_max, 8, dtype=torch.int64, device=dev)  # [grid][8] phase stamps, then [grid][8] per-wave loop-done
-    tn = [int(v) for v in args.tuning.split(",")]
-    lib.dasv_debug_set_tuning(tn[0], tn[1], tn[2], 0, tn[3])
+    tn = [int(v) for v in args.tuning.split(",")] + [0]
+    lib.dasv_debug_set_tuning(tn[0], tn[1], tn[2], tn[4], tn[3])
+    if args.nhwc:
+        lib.dasv_dmha_fwd_nhwc_f32.restype = ctypes.c_int
+        lib.dasv_dmha_fwd_nhwc_f32.argtypes = [vp] * 10 + [vp, csz, ci, ci, ci, ci, ci, vp]
     GRID = [0]
     stream = torch.cuda.current_stream().cuda_stream
 
     def launch(i, st):
         lib.dasv_debug_set_stamps(st)
-        rc = lib.dasv_dmha_fwd(0, xs[i % nbuf].data_ptr(), q.data_ptr(), None if args.no_att else a.data_ptr(), None, None,
+        if args.nhwc:
+            rc = lib.dasv_dmha_fwd_nhwc_f32(xs[i % nbuf].data_ptr(), q.data_ptr(), a.data_ptr(), None, None, out.data_ptr(),
+                                            None if args.no_align else align.data_ptr(), hw.data_ptr(), None, None,
+                                            ws.data_ptr(), ws.numel(), B, T, 5, D // 5, H, stream)
+        else:
+            rc = lib.dasv_dmha_fwd(0, xs[i % nbuf].data_ptr(), q.data_ptr(), None if args.no_att else a.data_ptr(), None, None,
                                out.data_ptr(), None if args.no_align else align.data_ptr(), hw.data_ptr(), ctx.data_ptr(),
                                ml.data_ptr(), ws.data_ptr(), ws.numel(), B, T, H, dh, T * D, D, stream)
         assert rc == 0, rc
