@@ -76,6 +76,15 @@ class _VGG(nn.Module):
         self.packed_activations = True
         # inference in the fp16-operand mode: activations between the layers as fp16 tensors (conv.conv3x3_f16)
         self.half_activations = True
+        # inference chains: convX2 + ReLU + the block's 2x2 ceil max-pool as ONE launch (conv.conv3x3_x8 / conv3x3_f16, pool=True).
+        # `fuse_pool_layers`: the (block, mode) pairs it is switched on for — where the same-process A/B on [64,300,80] says it pays
+        # (tools/_diag/pool_fuse_ab.py, profiles/r04_pool_fusion_ab.txt: split8 block 1 -1.3 %, block 2 -0.5 ... -1.4 %, both -2.4 %
+        # of the front-end's time; blocks 3 / 4 lose 0.4 / 2.4 % — tiles of whole row pairs leave 6-8 % of a 256-pixel tile idle and
+        # push their 760 / 1,500 workgroups into one more round of the 256 CUs, which costs more than their small pools save; with
+        # fp16 operands the convolutions are twice as fast and only block 2 breaks even).  Every (block, mode) pair runs and is tested.
+        self.fuse_pool = True
+        self.pool_tile = 0          # tile shape of the fused launches (0: automatic; measurements force 160 / 192 / 256)
+        self.fuse_pool_layers = {(1, "split8"), (2, "split8"), (2, "fp16")}
         self._packed = {}
 
     def _mode(self):
@@ -172,6 +181,14 @@ class _VGG(nn.Module):
                 h = _hipconv.conv3x3_x8(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_packed=True, y_packed=True, x_rec=rh, y_rec=ry)
                 rh = ry
             ry = next(r)
+            Bn, _, Hn, Wn = h.shape
+            if self.fuse_pool and (blk, "split8") in self.fuse_pool_layers and \
+                    _hipconv.pool_fusable("split8", Bn, Hn, Wn, c2.in_channels, c2.out_channels):
+                # conv + ReLU + max-pool in ONE launch: convX2's full-resolution map never reaches memory
+                h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=True,
+                                        y_packed=blk < self.n_blocks, x_rec=rh, y_rec=ry, pool=True, pool_tile=self.pool_tile)
+                rh = ry
+                continue
             h = _hipconv.conv3x3_x8(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_packed=True, y_packed=False, x_rec=rh, y_rec=ry)
             rh, ry = ry, next(r)
             h = _hipconv.maxpool2x2_ceil(h, pack=blk < self.n_blocks, x_rec=rh, y_rec=ry)
@@ -200,6 +217,13 @@ class _VGG(nn.Module):
                 h = _hipconv.conv3x3_f16(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_f16=True, y_f16=True, x_rec=rh, y_rec=ry)
                 rh = ry
             ry = next(r)
+            Bn, _, Hn, Wn = h.shape
+            if self.fuse_pool and (blk, "fp16") in self.fuse_pool_layers and \
+                    _hipconv.pool_fusable("fp16", Bn, Hn, Wn, c2.in_channels, c2.out_channels):
+                h = _hipconv.conv3x3_f16(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_f16=True, y_f16=blk < self.n_blocks,
+                                         x_rec=rh, y_rec=ry, pool=True, pool_tile=self.pool_tile)
+                rh = ry
+                continue
             h = _hipconv.conv3x3_f16(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_f16=True, y_f16=True, x_rec=rh, y_rec=ry)
             rh, ry = ry, next(r)
             h = _hipconv.maxpool2x2_ceil(h, pack=2 if blk < self.n_blocks else False, x_rec=rh, y_rec=ry)

@@ -75,6 +75,11 @@ SIGNATURES = {
     "dasv_conv3x3_bias_relu_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bias_relu_x8_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_pool_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dasv_conv3x3_bias_relu_pool_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_pool_f16_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_x8_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_dmha_nhwc_supported": (c_int, [c_int, c_int, c_int]),
     "dasv_dmha_fwd_nhwc_f32": (c_int, [c_void_p] * 10 + [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -112,8 +117,8 @@ def _bind(path, signatures):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
-    if lib.dasv_abi_version() != 2:
-        raise DasvError("%s ABI version %d, expected 2" % (path, lib.dasv_abi_version()))
+    if lib.dasv_abi_version() != 3:
+        raise DasvError("%s ABI version %d, expected 3" % (path, lib.dasv_abi_version()))
     return lib
 
 

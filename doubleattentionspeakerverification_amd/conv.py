@@ -18,7 +18,7 @@ from . import _lib
 
 __all__ = ["conv3x3_bias_relu", "PackedConvWeights", "invalidate_packed_weights", "supported", "conv3x3_c1_bias_relu", "maxpool2x2_ceil",
            "conv3x3_wgrad", "supported_wgrad", "conv3x3_c1_conv3x3_bias_relu", "conv3x3_x8",
-           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of", "conv3x3_f16"]
+           "maxpool2x2_ceil_autograd", "conv3x3_c1_bias_relu_autograd", "new_ranges", "range_of", "conv3x3_f16", "pool_fusable"]
 
 MODES = {"split": 0, "bf16": 1, "fp16": 2, "split8": 3}
 # "split8": fp32-grade on fewer matrix-pipe cycles (fp16 products + block-scaled e4m3 cross terms, csrc/conv3x3.hip X8).  Its
@@ -399,7 +399,13 @@ def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
     return y
 
 
-def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_rec=None, y_rec=None):
+def pool_fusable(mode, B, H, W, cin, cout):
+    """True when conv3x3 + bias + ReLU + 2x2 ceil max-pool runs as ONE launch for this layer (conv3x3_x8 / conv3x3_f16 with
+    pool=True): maps up to 80 columns with enough tiles that the launch does not want split-K."""
+    return exact(cin, cout) and bool(_lib.load().dasv_conv3x3_pool_supported(MODES[mode], B, H, W, cin, cout))
+
+
+def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_rec=None, y_rec=None, pool=False, pool_tile=0):
     """Inference-only relu(conv2d(x, weight, bias, padding 1)) in the split8 mode on PACKED activations.
 
     A packed tensor looks like the fp32 channels_last tensor it replaces (same shape, dtype, strides; C % 64 == 0) but every
@@ -408,7 +414,9 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_r
     store_x8).  Made once by the producer — this function with y_packed=True, conv3x3_c1_bias_relu(pack=True),
     maxpool2x2_ceil(pack=True) — it turns the consumer's staging into a copy.  Only these three functions understand packed
     tensors: never hand one to a torch op.  x_rec: the record of x (required for a packed x; measured when None otherwise);
-    y_rec: the record of y (required for a packed y)."""
+    y_rec: the record of y (required for a packed y).
+    pool=True (see pool_fusable): F.max_pool2d(relu(conv(x)), 2, stride=2, ceil_mode=True) in the same launch — y is the pooled
+    map [B, Cout, ceil(H/2), ceil(W/2)] and the full-resolution map never reaches memory (CNNs.py:73-74 ... 85-86)."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = weight.shape[0]
@@ -426,6 +434,15 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_r
         x_rec = range_of(x)
     if y_packed and y_rec is None:
         raise RuntimeError("a packed output needs a range record (conv.new_ranges)")
+    if pool:
+        y = torch.empty((B, cout, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_bias_relu_pool_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                         None if bias is None else bias.detach().data_ptr(), y.data_ptr(), int(y_packed),
+                                                         None if y_rec is None else y_rec.data_ptr(), B, H, W, cin, cout, int(pool_tile),
+                                                         torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_x8_nhwc")
+        return y
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
@@ -439,7 +456,7 @@ def conv3x3_x8(x, weight, bias, packed=None, x_packed=False, y_packed=False, x_r
     return y
 
 
-def conv3x3_f16(x, weight, bias, packed=None, x_f16=False, y_f16=False, x_rec=None, y_rec=None):
+def conv3x3_f16(x, weight, bias, packed=None, x_f16=False, y_f16=False, x_rec=None, y_rec=None, pool=False, pool_tile=0):
     """Inference-only relu(conv2d(x, weight, bias, padding 1)) with fp16 operands on HALF-PRECISION activation tensors.
 
     A half-precision tensor is what the fp32 channels_last tensor would be with 2-byte elements: [B,H,W,C] fp16 in NHWC memory
@@ -460,6 +477,16 @@ def conv3x3_f16(x, weight, bias, packed=None, x_f16=False, y_f16=False, x_rec=No
         x_rec = range_of(x)
     if y_f16 and y_rec is None:
         raise RuntimeError("a half-precision output needs a range record (conv.new_ranges)")
+    if pool:      # the 2x2 ceil max-pool in the same launch (conv3x3_x8's docstring): y is the pooled map
+        y = torch.empty((B, cout, (H + 1) // 2, (W + 1) // 2), dtype=torch.float16 if y_f16 else torch.float32, device=x.device,
+                        memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_bias_relu_pool_f16_nhwc(x.data_ptr(), int(x_f16), x_rec.data_ptr(), hi.data_ptr(),
+                                                          None if bias is None else bias.detach().data_ptr(), y.data_ptr(), int(y_f16),
+                                                          None if y_rec is None else y_rec.data_ptr(), B, H, W, cin, cout, int(pool_tile),
+                                                          torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_f16_nhwc")
+        return y
     y = torch.empty((B, cout, H, W), dtype=torch.float16 if y_f16 else torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         nws = 0 if y_f16 else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)

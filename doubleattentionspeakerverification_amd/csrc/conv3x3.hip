@@ -258,6 +258,11 @@ struct ConvParams {
     const float* mel;      // [B,H,W]
     const float* w1;       // [Cin][9]
     const float* b1;       // [Cin] or null
+    // fused 2x2 stride-2 ceil-mode max-pool (CNNs.py:40,44,48 / 74,78,82,86 behind convX2: `pool(relu(convX2(.)))` in one launch,
+    // pipelined launches only): y is the POOLED tensor [B, ceil(H/2), ceil(W/2), Cout] in the form y_packed names.  A tile then
+    // covers `pool_units` whole ROW PAIRS (units; the last unit of an image with an odd H is a single row) instead of TBM raster
+    // pixels, so that every 2x2 window lies inside one tile: pool_units * 2 * W <= TBM, pool_U = ceil(H/2) units per image.
+    int pool, pool_units, pool_U;
 };
 
 // LDS: four planes of 128 rows x 128 bytes (64 bf16): A_hi | A_lo | B_hi | B_lo.  16-byte slot s of row r lives at
@@ -427,19 +432,24 @@ constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 51
 // into conv12: its 786 MB output never exists in HBM).
 // IB = 16-pixel blocks per wave along the pixels: 4 -> 256-pixel tiles; 3 -> 192-pixel tiles, whose window leaves room for both
 // tile buffers on 80-column maps (90.6 KB + 64 KB), so conv12 runs the pipelined double-buffered loops too.
-template <int PREC, bool DBUF, bool C1, int NWN, int IB = 4>
-__global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvParams p) {
-    static_assert(IB == 4 || (IB == 3 && NWN == 2 && !C1), "192-pixel tiles: 8-wave layout, activations from memory");
-    constexpr int TBM = 64 * IB;   // pixels per workgroup tile (4 waves along the pixels x IB blocks of 16)
+// WM = waves along the pixels (x NWN along the 128 output channels).  WM = 2, NWN = 4, IB = 5: eight waves of 80 pixels x 32 channels
+// = 160-pixel tiles — a whole ROW PAIR of an 80-column map (and 2 / 4 / 8 pairs of the 40- / 20- / 10-column ones), the tile shape of
+// the fused max-pool epilogue (ConvParams::pool) that wastes no pixel rows of the matrix work.
+template <int PREC, bool DBUF, bool C1, int NWN, int IB = 4, int WM = 4>
+__global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const ConvParams p) {
+    static_assert((WM == 4 && (IB == 4 || (IB == 3 && NWN == 2 && !C1))) || (WM == 2 && NWN == 4 && IB == 5 && !C1 && DBUF),
+                  "256-pixel tiles; 192-pixel tiles: 8-wave layout, activations from memory; 160-pixel tiles: 2 x 4 waves, pipelined");
+    constexpr int TBM = 16 * IB * WM;   // pixels per workgroup tile (WM waves along the pixels x IB blocks of 16)
     // NWN waves along the 128 output channels (x 4 along the 256 pixels): 2 -> 8 waves of 64 x 64 outputs, 4 -> 16 waves of
     // 64 x 32 (more waves per SIMD to overlap each other's barrier / fragment-read waits, at more LDS reads per MFMA)
     static_assert(NWN == 2 || NWN == 4, "wave layout");
     static_assert(!C1 || NWN == 2, "the fused first layer stages with the 512-thread layout");
-    constexpr int NT = 256 * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = ((64 * IB + 2 * 80 + 2) * 16 + NT - 1) / NT, BCH = 1024 / NT;
+    constexpr int NT = 64 * WM * NWN, JT = 8 / NWN, NPW = 128 / NWN, WACHN = ((TBM + 2 * 80 + 2) * 16 + NT - 1) / NT, BCH = 1024 / NT;
+    constexpr bool W8 = WM * NWN == 8;      // eight waves: the pipelined loops (the tile's DMA is divided over eight waves)
     constexpr bool X8 = PREC == PREC_X8;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
     constexpr bool TWO = SPLIT || X8;      // two LDS planes per operand: bf16 hi | lo, or fp16 hi | the two e4m3 planes
-    static_assert(!X8 || (NWN == 2 && !C1), "the fp16 + e4m3 mode exists for the 8-wave layout, activations from memory");
+    static_assert(!X8 || (W8 && !C1), "the fp16 + e4m3 mode exists for the 8-wave layouts, activations from memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int W = p.W, H = p.H, Cin = p.Cin;
@@ -450,7 +460,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // 128 zero bytes behind the tile buffers (pipelined loops): a border tap reads its fragment from here — ONE address select per
     // fragment instead of a data select per fragment register (probe: the selects cost 45 ns of a 1.9 us tap)
     char* Zrow = Bbase + (DBUF ? 65536 : 32768);
-    if (DBUF && NWN == 2 && !C1 && threadIdx.x < 8)
+    if (DBUF && W8 && !C1 && threadIdx.x < 8)
         *reinterpret_cast<u32x4*>(Zrow + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};   // visible after the first barrier of the loop
 
     const int per_split = p.tiles_per_xcd * 8;
@@ -479,7 +489,16 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 #else
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
 #endif
-    const int m0 = mt * TBM, n0 = nt * CBN;
+    int m0 = mt * TBM, mend = p.M;
+    const int n0 = nt * CBN;
+    int pu0 = 0, pu1 = 0;          // fused pool: the tile's units [pu0, pu1)
+    if (p.pool) {
+        pu0 = mt * p.pool_units;
+        pu1 = min(pu0 + p.pool_units, p.B * p.pool_U);
+        const int b0 = pu0 / p.pool_U, b1 = pu1 / p.pool_U;
+        m0 = (b0 * H + 2 * (pu0 - b0 * p.pool_U)) * W;
+        mend = pu1 == p.B * p.pool_U ? p.M : (b1 * H + 2 * (pu1 - b1 * p.pool_U)) * W;
+    }
     DASV_STAMP(0);
 
     // border masks of this lane's four A-fragment pixels
@@ -488,7 +507,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     for (int i = 0; i < IB; ++i) {
         const int m = m0 + wm * (16 * IB) + i * 16 + frow;
         unsigned mask = 0;
-        if (m < p.M) {
+        if (m < mend) {
             const int w_ = m % W;
             int h_ = (m / W) % H, hend = H;
             if (p.row_span != nullptr) {      // ragged: row m / W belongs to the utterance spanning rows [lo, hi)
@@ -795,7 +814,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
 
     // split-K: this workgroup covers channel slabs [sl_lo, nslab) of the Cin / 64
     const int sl_lo = (Cin / CBK) * ks / p.ksplit, nslab = (Cin / CBK) * (ks + 1) / p.ksplit;
-    constexpr bool PIPELINED = DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    constexpr bool PIPELINED = DBUF && W8 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPELINED) dma_b(Bbase, 0, sl_lo * CBK);
     else load_b(0, sl_lo * CBK);
     int it = 0;
@@ -806,7 +825,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
     // multiply: two exposed read phases per tap.  tools/conv_core_probe.hip (same loop, LDS only): 2049 -> 1882 ns per tap.
     // Needs 128 fragment registers: possible since the window staging addresses stopped occupying ~60 registers (above).
     // (the single-MFMA modes, bf16 / fp16 operands, run the same loop on their one plane per operand)
-    constexpr bool PIPE = !X8 && DBUF && NWN == 2 && !C1 && DASV_CONV_DIAG == 0;
+    constexpr bool PIPE = !X8 && DBUF && W8 && !C1 && DASV_CONV_DIAG == 0;
     if constexpr (PIPE) {
         struct Frags { bf16x8 bh[JT], bl[SPLIT ? JT : 1], ah[IB], al[SPLIT ? IB : 1]; };
         const int brow = wn * NPW + frow;
@@ -888,7 +907,7 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 mma_rows(fb, 2, IB);
             }
         }
-    } else if constexpr (X8 && DBUF && NWN == 2 && DASV_CONV_DIAG == 0) {
+    } else if constexpr (X8 && DBUF && W8 && DASV_CONV_DIAG == 0) {
         // The same software pipeline for the fp16 + e4m3 mode.  Per tap three MFMA groups: fp16 half 0, fp16 half 1 (16 MFMAs of 16
         // cycles each), e4m3 cross terms (16 MFMAs of 32 cycles).  The fragments of fp16 half 1 and the e4m3 fragments are read at
         // the top of the tap, while half 0 (fetched during the previous tap) is multiplied; the NEXT tap's half-0 fragments while
@@ -986,15 +1005,24 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 // after that (pixel e4m3 fragments; the next tap's first-half pixel fragments beside the e4m3 group).  Left alone
                 // the scheduler emits each group as a block behind a block of reads and an lgkmcnt(0): both waves of a SIMD read,
                 // then both multiply
+                if constexpr (WM == 4) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                    for (int k = 0; k < 16; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
 #pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    for (int k = 0; k < 12; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    // 5 x 2 tiles per wave: 10 MFMAs per group, 21 reads at the top of the tap + 5 for the next tap's pixels
+#pragma unroll
+                    for (int k = 0; k < 3 * (IB + JT) + IB; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                 }
 #endif
                 if (tap < 8) {
@@ -1201,9 +1229,12 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
                 for (int i = 0; i < IB; ++i) {
                     f32x4 v = (SCALED ? acc[i][j] * sc : acc[i][j]) + bv;
                     if (p.relu) v = relu4(v);
-                    if (m0 + wm * (16 * IB) + i * 16 + (lane & 15) < p.M) note4(v);
+                    if (m0 + wm * (16 * IB) + i * 16 + (lane & 15) < mend) note4(v);
                     char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
-                    if (PREC == PREC_F16 && p.y_packed == 2) {
+                    if (p.pool) {
+                        // fused max-pool: the image holds the fp32 values; the output form is applied to the pooled values below
+                        *reinterpret_cast<f32x4*>(row + nl * 4) = v;
+                    } else if (PREC == PREC_F16 && p.y_packed == 2) {
                         const f32x4 q = v * sy;
                         const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
                         *reinterpret_cast<uint2*>(row + nl * 2) = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
@@ -1229,6 +1260,46 @@ __global__ void __launch_bounds__(256 * NWN) conv3x3_window_kernel(const ConvPar
             __syncthreads();
             DASV_STAMP(62);
             if (p.y_rec != nullptr && tid == 0 && s_amax > rec_seen) atomicMax(p.y_rec, s_amax);
+            if (p.pool) {
+                // 2x2 stride-2 ceil-mode max-pool of the tile's row pairs out of the LDS image (F.max_pool2d(., 2, stride=2,
+                // ceil_mode=True), CNNs.py:74-86): a thread takes four channels of one pooled pixel — 32 threads a pixel's 128
+                // channels — compares the window's up to four pixels (a NaN takes over, as in torch; strict '>': values only, no
+                // indices here) and stores the pooled pixel in the output form: fp32, PACKED (same conversion the stand-alone pool
+                // applies, scaled by the exponent of THIS layer's output bound since the true maximum is not known before the last
+                // tile has finished) or fp16.  The full-resolution map never reaches memory.
+                const int Wo = (W + 1) >> 1, Ho = (H + 1) >> 1, U = p.pool_U;
+                const int npool = (pu1 - pu0) * Wo;
+                const int col = tid & 31;
+                auto mx4 = [](f32x4 a, f32x4 v) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = (v[c] > a[c] || v[c] != v[c]) ? v[c] : a[c];
+                    return a;
+                };
+                for (int q = tid >> 5; q < npool; q += NT / 32) {
+                    const int j = q / Wo, c = q - j * Wo;
+                    const int u = pu0 + j, b = u / U, k = u - b * U;
+                    const int lp = (b * H + 2 * k) * W + 2 * c - m0;          // the window's first pixel inside the tile
+                    const bool c1 = 2 * c + 1 < W, r1 = 2 * k + 1 < H;
+                    const char* src = smem + lp * OP + col * 16;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                    if (c1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + OP));
+                    if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + W * OP));
+                    if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (W + 1) * OP));
+                    const long long op = ((long long)b * Ho + k) * Wo + c;
+                    if (PREC == PREC_F16 && p.y_packed == 2) {
+                        const f32x4 qv = v * sy;
+                        const f16x2_t a = __builtin_convertvector(f32x2_t{qv[0], qv[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{qv[2], qv[3]}, f16x2_t);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)op * p.Cout + n0 + col * 4) * 2) =
+                            make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                    } else if (p.y_packed) {
+                        store_x8(p.y, op, p.Cout, n0 + col * 4, v, sy);
+                    } else {
+                        *reinterpret_cast<f32x4*>(p.y + (size_t)op * p.Cout + n0 + col * 4) = v;
+                    }
+                }
+                DASV_STAMP(63);
+                return;
+            }
             if (PREC == PREC_F16 && p.y_packed == 2) {
                 // half-precision rows: 256 bytes per pixel and 128-channel tile, 32 pixels per pass of the workgroup
                 const int col16 = tid & 15;
@@ -1410,7 +1481,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
                           const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, const uint32_t* x_rec = nullptr,
-                          uint32_t* y_rec = nullptr) {
+                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1432,13 +1503,16 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
     if ((x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
     p.row_span = row_span;
+    p.pool = 0; p.pool_units = 0; p.pool_U = 0;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
+    // fused max-pool: dense batches, plain epilogue (no mask / column sums / split-K), relu'd outputs
+    if (pool && (row_span != nullptr || mask != nullptr || colsum != nullptr || mel != nullptr || W > 80 || !relu)) return DASV_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     p.ntiles = Cout / dasv::CBN;
     if (W <= 80) {
         // split-K needs the caller's workspace (and has no column-sum / fused-first-layer form): without it, one pass
         // (a packed output is written by the convolution's own epilogue: no split-K form)
-        const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr && !y_packed) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
+        const int S = (colsum == nullptr && mel == nullptr && workspace != nullptr && !y_packed && !pool) ? dasv::conv3x3_ksplit(B, H, W, Cin, Cout) : 1;
         const bool two = mode == 0 || mode == 3;
         const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
         const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
@@ -1449,13 +1523,37 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           colsum == nullptr && mel == nullptr;
         const int tbm = t192 ? 192 : dasv::WBM;
         p.mtiles = (p.M + tbm - 1) / tbm;
-        p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         const size_t lds1 = t192 ? lds192 : lds256;
         // both tile buffers (stride 32 KB also for the one-plane modes) whenever they fit: the launch then runs the pipelined loops
         // (round 1 measured the double buffer alone as a loss for bf16 operands — with the un-pipelined loop)
         const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
+        bool t160 = false;
+        if (pool) {
+            // tiles of whole row pairs (the pooled tile is formed in the coalescing epilogue's LDS image: pipelined launches only).
+            // Tile shape: 256 (192) pixels of which `big` hold whole row pairs, or 160 pixels (2 x 4 waves of 80 x 32 outputs),
+            // which hold the row pairs of 80-, 40-, 20- and 10-column maps exactly.  Measured (tools/_diag/pool_fuse_ab.py,
+            // profiles/r04_pool_fusion_ab.txt): per pixel the 160-pixel layout is ~17 % slower than the 64 x 64 wave tiles (more
+            // fragment reads per MFMA, the weight tile staged per 160 pixels), so it only pays where the big tile would waste more
+            // than a fifth of its rows (fp16 operands on 80 columns: 160 of 256).  pool_tile forces one (0: automatic).
+            const int big = (dbuf && 2 * W <= tbm) ? tbm / (2 * W) * 2 * W : 0;            // pixels used of the big tile
+            const int small = (mode == 2 || mode == 3) && 2 * W <= 160 ? 160 / (2 * W) * 2 * W : 0;
+            if (pool_tile == 160) t160 = small > 0;
+            else if (pool_tile == 0) t160 = small > 0 && (big == 0 || big * 5 < tbm * 4);
+            if (pool_tile != 0 && pool_tile != 160 && pool_tile != tbm) return DASV_E_SHAPE;
+            if (!t160 && big == 0) return DASV_E_SHAPE;
+            if (pool_tile == 160 && !t160) return DASV_E_SHAPE;
+            p.pool = 1;
+            p.pool_units = (t160 ? 160 : tbm) / (2 * W);
+            p.pool_U = (H + 1) / 2;
+            p.mtiles = (int)(((long long)B * p.pool_U + p.pool_units - 1) / p.pool_units);
+        }
+        p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         if (dbuf && lds < (size_t)tbm * 528) lds = (size_t)tbm * 528;   // the coalescing epilogue's [pixel][528 B] image (narrow maps)
+        if (t160) {
+            lds = (size_t)(160 + 2 * W + 2) * 128 * (two ? 2 : 1) + 65536 + 128;
+            if (lds < (size_t)160 * 528) lds = (size_t)160 * 528;
+        }
         if (S > 1) {
             if (workspace_bytes < (size_t)S * p.M * Cout * sizeof(float)) return DASV_E_WORKSPACE;
             p.part = static_cast<float*>(workspace);
@@ -1468,11 +1566,13 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, DB, CC, nwn_, ##__VA_ARGS__>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (e != hipSuccess) return (int)e;                                                                      \
-            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC, nwn_, ##__VA_ARGS__>), grid, dim3(256 * nwn_), lds, s, p); \
+            hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, DB, CC, nwn_, ##__VA_ARGS__>), grid, dim3(t160 ? 512 : 256 * nwn_), lds, s, p); \
         } while (0)
         // wave layout: 8 waves (64 x 64 outputs each) everywhere except the single-buffered split launches (80-column maps:
         // two barriers per tap), where 16 waves of 64 x 32 hide each other's waits: conv12 1.32 -> 1.20 ms (interleaved A/B)
-        if (p.mel != nullptr) {
+        if (t160 && mode == 3) DASV_LAUNCH_WINDOW(3, true, false, 4, 5, 2);
+        else if (t160) DASV_LAUNCH_WINDOW(2, true, false, 4, 5, 2);
+        else if (p.mel != nullptr) {
             if (mode == 0 && dbuf) DASV_LAUNCH_WINDOW(0, true, true, 2);
             else if (mode == 0) DASV_LAUNCH_WINDOW(0, false, true, 2);
             else if (mode == 1) DASV_LAUNCH_WINDOW(1, false, true, 2);
@@ -1537,6 +1637,37 @@ int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* 
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
                           static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
                           x_packed ? 1 : 0, y_packed ? 1 : 0, x_range, y_range);
+}
+
+int dasv_conv3x3_pool_supported(int mode, int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || W > 80 || Cin <= 0 || Cout <= 0 || Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return 0;
+    if (mode != 2 && mode != 3) return 0;
+    // few tiles (single utterances): those launches divide their channel slabs over workgroups instead (split-K, no fused pool)
+    if (dasv::conv3x3_ksplit(B, H, W, Cin, Cout) > 1) return 0;
+    const bool two = mode == 3;
+    const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
+    const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
+    const bool t192 = two && lds256 + 32768 + 128 > 160 * 1024 && lds192 + 32768 + 128 <= 160 * 1024;
+    const size_t lds1 = t192 ? lds192 : lds256;
+    return 2 * W <= 160 || (lds1 + 32768 + 128 <= 160 * 1024 && 2 * W <= (t192 ? 192 : dasv::WBM));
+}
+
+int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                        const float* bias, void* y, int y_packed, uint32_t* y_range, int B, int H, int W, int Cin,
+                                        int Cout, int tile_pixels, dasv_stream_t stream) {
+    if (!dasv_conv3x3_pool_supported(3, B, H, W, Cin, Cout)) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
+                          static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, 1, stream, nullptr, x_packed ? 1 : 0,
+                          y_packed ? 1 : 0, x_range, y_range, 1, tile_pixels);
+}
+
+int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
+                                         void* y, int y_f16, uint32_t* y_range, int B, int H, int W, int Cin, int Cout,
+                                         int tile_pixels, dasv_stream_t stream) {
+    if (!dasv_conv3x3_pool_supported(2, B, H, W, Cin, Cout)) return DASV_E_SHAPE;
+    return conv3x3_launch(2, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, nullptr, bias, nullptr, nullptr,
+                          static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, 1, stream, nullptr, x_f16 ? 2 : 0,
+                          y_f16 ? 2 : 0, x_range, y_range, 1, tile_pixels);
 }
 
 #if DASV_CONV_STAMPS

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DASV_ABI_VERSION 2
+#define DASV_ABI_VERSION 3
 
 #define DASV_OK            0
 #define DASV_E_NULL       -1  /* a required pointer is NULL */
@@ -313,6 +313,24 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
 int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
                                    const float* bias, void* y, int y_packed, uint32_t* y_range, void* workspace, size_t workspace_bytes,
                                    int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+/* conv3x3 + bias + ReLU + 2x2 stride-2 ceil-mode max-pool in ONE launch: `F.max_pool2d(F.relu(self.convX2(h)), 2, stride=2,
+ * ceil_mode=True)` (CNNs.py:39-40, 43-44, 47-48 / 73-74, 77-78, 81-82, 85-86).  y is the POOLED tensor
+ * [B, ceil(H/2), ceil(W/2), Cout] — fp32, packed or fp16 like the un-pooled entry points' y; the full-resolution map never reaches
+ * memory.  A workgroup's tile is a whole number of row pairs of one or more images, the pooled pixels are formed from the tile's
+ * fp32 values before the output conversion (so the pooled values are exactly those of the two-launch form; a PACKED / fp16 output is
+ * scaled by this layer's output BOUND like the un-pooled packed output — the stand-alone pool knows the exact maximum — which changes
+ * the operand planes of the next layer by less than their own rounding).  y_range as above (its [0] = max |y|).
+ * dasv_conv3x3_pool_supported(mode 2 | 3, ...): 1 when the launch exists for the shape (maps up to 80 columns, enough tiles that the
+ * channel slabs need not be divided over workgroups); callers use the un-pooled entry point + dasv_maxpool2x2_ceil_* otherwise.
+ * tile_pixels: 0 = the tile shape that wastes the fewest pixel rows (160 pixels = whole row pairs of 80- / 40- / 20- / 10-column
+ * maps, else 256 / 192); 160 or 256 / 192 force one (A/B measurements; DASV_E_SHAPE when it does not exist for the shape). */
+int dasv_conv3x3_pool_supported(int mode, int B, int H, int W, int Cin, int Cout);
+int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                        const float* bias, void* y, int y_packed, uint32_t* y_range, int B, int H, int W, int Cin,
+                                        int Cout, int tile_pixels, dasv_stream_t stream);
+int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
+                                         void* y, int y_f16, uint32_t* y_range, int B, int H, int W, int Cin, int Cout,
+                                         int tile_pixels, dasv_stream_t stream);
 int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,

@@ -59,7 +59,7 @@ def test_binding_table_covers_the_header(lib_path):
     from doubleattentionspeakerverification_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.dasv_abi_version() == 2
+    assert lib.dasv_abi_version() == 3
     assert lib.dasv_error_string(-3) == b"workspace missing or too small"
     assert lib.dasv_dmha_workspace_bytes(64, 300, 8, 64) >= 64 * 4
     assert lib.dasv_dmha_bwd_workspace_bytes(64, 300, 8, 64) >= 64 * 512 * 4

@@ -337,6 +337,99 @@ def test_split8_masked_data_gradient_vs_fp64(cin, cout, H, W, B):
     assert float((gott.cpu().double() - reft).abs().max()) / float(reft.abs().max()) < 6.2e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 37, 80, 3), (64, 128, 38, 80, 2), (64, 256, 75, 40, 3), (128, 128, 150, 40, 16),
+                                           (64, 128, 75, 20, 5), (64, 128, 38, 10, 7), (64, 128, 1, 10, 9), (64, 128, 5, 1, 3),
+                                           (64, 128, 7, 33, 4), (64, 128, 2, 2, 1)])
+def test_conv_relu_maxpool_in_one_launch_equals_the_two_launch_form(cin, cout, H, W, B):
+    """`F.max_pool2d(F.relu(convX2(h)), 2, stride=2, ceil_mode=True)` (CNNs.py:73-74 ... 85-86) as ONE launch
+    (dasv_conv3x3_bias_relu_pool_x8_nhwc / _f16_nhwc): tiles of whole row pairs, the pooled pixels formed from the tile's fp32
+    values.  Against the two-launch form (same convolution arithmetic, so the fp32 pooled map must be IDENTICAL) and against a
+    float64 convolution + torch's ceil-mode pool; odd heights and widths (clipped windows), images whose row pairs straddle tiles,
+    single rows / columns, packed and plain inputs, packed / fp16 / fp32 outputs."""
+    from doubleattentionspeakerverification_amd import conv
+    w = torch.from_numpy(rnd(2, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    bias = torch.from_numpy(rnd(3, cout, scale=0.1)).to(DEV)
+    x = torch.relu(torch.from_numpy(rnd(1, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.max_pool2d(_conv64(x, w, bias, relu=True), 2, stride=2, ceil_mode=True)
+    pk = conv.PackedConvWeights()
+    assert conv.pool_fusable("split8", B, H, W, cin, cout) and conv.pool_fusable("fp16", B, H, W, cin, cout)
+    with torch.no_grad():
+        recs = conv.new_ranges(x.device, 8)
+        recs[0] = conv.range_of(x)
+        two = conv.maxpool2x2_ceil(conv.conv3x3_x8(x, w, bias, pk, x_rec=recs[0], y_rec=recs[1]))
+        one = conv.conv3x3_x8(x, w, bias, pk, x_rec=recs[0], y_rec=recs[2], pool=True)
+        assert one.shape == two.shape == ref.shape and torch.equal(one, two)
+        # both tile shapes: 160 pixels (2 x 4 waves of 80 x 32 outputs: whole row pairs of 80 / 40 / 20 / 10 columns) and 256 / 192
+        shapes = 0
+        for tile in (160, 192, 256):
+            try:
+                t1 = conv.conv3x3_x8(x, w, bias, pk, x_rec=recs[0], pool=True, pool_tile=tile)
+                t2 = conv.conv3x3_f16(x, w, bias, None, x_rec=recs[0], pool=True, pool_tile=tile if tile != 192 else 256)
+            except Exception:
+                continue
+            shapes += 1
+            assert torch.equal(t1, two), tile
+            assert _rel(t2.cpu(), ref) < 1.25e-3, tile
+        assert shapes >= 2
+        assert int(recs[2, 0]) == int(recs[1, 0])                     # the record holds the maximum of the full-resolution map
+        assert _rel(one.cpu(), ref) < 4e-5
+        # a packed input (made by conv11 / a pool in the chain) and a packed pooled output, consumed by a following convolution
+        big = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest").contiguous(memory_format=torch.channels_last)
+        rb = conv.range_of(big)
+        xp = conv.maxpool2x2_ceil(big, pack=True, x_rec=rb, y_rec=recs[3])       # == x, packed
+        onep = conv.conv3x3_x8(xp, w, bias, pk, x_packed=True, x_rec=recs[3], y_rec=recs[4], pool=True)
+        assert torch.equal(onep, one)
+        w2 = torch.from_numpy(rnd(4, 128, cout, 3, 3, scale=(2.0 / (9 * cout)) ** 0.5)).to(DEV)
+        pk2 = conv.PackedConvWeights()
+        yp = conv.conv3x3_x8(xp, w, bias, pk, x_packed=True, y_packed=True, x_rec=recs[3], y_rec=recs[5], pool=True)
+        nxt = conv.conv3x3_x8(yp, w2, None, pk2, x_packed=True, x_rec=recs[5], y_rec=recs[6])
+        ref2 = _conv64(ref.float(), w2, None, relu=True)
+        assert _rel(nxt.cpu(), ref2) < 5e-5
+        # fp16-operand mode: fp32 pooled map identical to its own two-launch form; fp16 pooled tensor within fp16 rounding
+        pkh = conv.PackedConvWeights()
+        rh = conv.new_ranges(x.device, 4)
+        two_h = conv.maxpool2x2_ceil(conv.conv3x3_f16(x, w, bias, pkh, x_rec=recs[0], y_rec=rh[0]))
+        one_h = conv.conv3x3_f16(x, w, bias, pkh, x_rec=recs[0], y_rec=rh[1], pool=True)
+        assert torch.equal(one_h, two_h) and _rel(one_h.cpu(), ref) < 1.25e-3
+        half = conv.conv3x3_f16(x, w, bias, pkh, y_f16=True, x_rec=recs[0], y_rec=rh[2], pool=True)
+        back = conv.maxpool2x2_ceil(torch.nn.functional.interpolate(half, scale_factor=2, mode="nearest").contiguous(
+            memory_format=torch.channels_last), x_rec=rh[2], y_rec=rh[3])          # fp16 tensor -> fp32 (unscaled) through the pool
+        assert _rel(back.cpu(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("T", [299, 300, 301, 150])
+def test_fused_pool_chain_vs_oracle_front_end(T, monkeypatch):
+    """The inference chains with every block's pool fused into its convX2 launch (default model, B = 16: the chain a [64,300,80]
+    batch takes) against oracle.vgg_forward (CNNs.py:68-91) for T = 299 / 300 / 301 (odd maps at different levels, ceil mode);
+    a spy sees NO stand-alone pool launch; the un-fused chain agrees to rounding."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    from doubleattentionspeakerverification_amd import conv
+    torch.manual_seed(9)
+    net = VGG4L(1024).to(DEV).eval()
+    sd = {"front_end." + k: v.detach().cpu() for k, v in net.state_dict().items()}
+    B = 16 if T >= 299 else 32                  # (enough tiles in the last block that no launch wants split-K)
+    x = torch.from_numpy(rnd(82, B, T, 80))
+    calls = []
+    real = conv.maxpool2x2_ceil
+    monkeypatch.setattr(conv, "maxpool2x2_ceil", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = oracle.vgg_forward(x[:2], sd, 4)
+        for mode, bar in (("split8", 5e-5), ("fp16", 4e-3)):
+            net.conv_mode = mode
+            net.fuse_pool_layers = {(blk, mode) for blk in (1, 2, 3, 4)}      # every block fused (the default fuses where it pays)
+            assert net.fuse_pool and net._packed_chain_ok(80, B, T)
+            del calls[:]
+            y = net(x.to(DEV)).cpu()
+            assert not calls, "%d stand-alone pool launches in the fused %s chain" % (len(calls), mode)
+            net.fuse_pool = False
+            y0 = net(x.to(DEV)).cpu()
+            net.fuse_pool = True
+            assert len(calls) == 4
+            assert y.shape[1:] == ref.shape[1:] and _rel(y[:2], ref) < bar, (mode, T, _rel(y[:2], ref))
+            assert _rel(y, y0) < bar
+
+
 def test_fp16_activation_chain_vs_oracle_and_range():
     """BASELINE config 3 names bf16 and config 5 the "fp16 MFMA path": with conv_mode "fp16" the inference front-end stores its
     activations as fp16 tensors between the layers (2 bytes per element, scaled per tensor by range records: conv.conv3x3_f16).
