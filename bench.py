@@ -327,6 +327,52 @@ def mfma_util_pmc():
         return None
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def companion_workloads():
+    """BASELINE configs 3/4 and 5 inside the driver-timed line: after the headline's timed regions (never inside them, never in
+    `value`), this script runs itself as a child process for the training step (`--workload train`: forward + AM-softmax/CE + backward +
+    Adam on [64,300,80], 5994 speakers) and for the variable-length pass on the fp16 MFMA path (`--workload varlen --conv fp16`: 1,024
+    utterances of 150..800 frames, ragged packing), and keeps each child's value, step time and roofline.  The parent's GPU work is
+    finished and synchronised before a child starts; a child that fails is reported as such, not hidden."""
+    import subprocess
+    out = {}
+    runs = {"train (BASELINE config 3/4 on one GPU)": ["--workload", "train", "--steps", "20", "--warmup", "5", "--regions", "5"],
+            "varlen_fp16 (BASELINE config 5 on one GPU)": ["--workload", "varlen", "--conv", "fp16", "--steps", "3", "--warmup", "1", "--regions", "3"]}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-companions", "--no-power-probe"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+                continue
+            d = json.loads(line[-1])
+            keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in d}
+            keep["regions_elapsed_s"] = d.get("regions", {}).get("elapsed_s")
+            keep["workload"] = d.get("config", {}).get("workload")
+            roof = d.get("roofline") or {}
+            keep["roofline"] = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                                     "mfma_executed_frac") if k in roof}
+            if "weight_gradient" in roof:
+                keep["roofline"]["weight_gradient"] = {k: roof["weight_gradient"][k] for k in ("kernel", "achieved", "frac", "avg_launch_us",
+                                                                                               "launches_per_step") if k in roof["weight_gradient"]}
+            keep["child_wall_s"] = round(time.perf_counter() - t0, 1)
+            out[name] = keep
+        except (subprocess.TimeoutExpired, ValueError, OSError) as e:
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -358,7 +404,7 @@ def cpu_baseline_embed(params, frames, seconds=12.0):
             if time.perf_counter() - t0 > seconds:
                 break
         dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port", cpu_model=cpu_model(),
                 sample="%d utterances of [%d,80] through oracle.embedding_forward (torch CPU fp32, op-sequence "
                        "restatement of model.py:52-59), %.1f s" % (n, frames, dt))
 
@@ -379,7 +425,7 @@ def cpu_baseline_pool(B, T, D, H, seconds=10.0):
             if time.perf_counter() - t0 > seconds:
                 break
         dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=n / dt, unit="utterance-embeddings/s", cores=torch.get_num_threads(), kind="port", cpu_model=cpu_model(),
                 sample="%d utterances of [%d,%d] through oracle.dmha_opseq (torch CPU fp32, the reference's op "
                        "sequence poolings.py:73-80,45-51), %.1f s" % (n, T, D, dt))
 
@@ -455,6 +501,9 @@ def main():
                          "cross terms (split8, default: ~1e-5 of the output scale per layer) or split-bf16 operands (split: ~5e-6), "
                          "single-MFMA bf16 / fp16 operands, or PyTorch-ROCm/MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true",
+                    help="skip `companion_workloads` (the training step and the variable-length fp16 pass timed by child runs of this "
+                         "script after the headline's regions; profiling runs and the children themselves pass this)")
     ap.add_argument("--no-power-probe", action="store_true", help="skip roofline.power_probe (profiling runs: its 200 launches would mix into the kernel statistics)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for real runs; gloo only to rehearse the multi-rank path on one GPU")
@@ -656,7 +705,8 @@ def main():
             ach = ab2 / c2_us / 1e3
             pool_roof = {"kernel": "dasv::dmha_fwd_vec (fused DoubleMHA forward)", "bound": "hbm", "achieved": round(ach, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("pool", "fp32"), "algorithmic_bytes_per_launch": ab2,
+                         "traffic": pmc_traffic("pool", "fp32"), "traffic_source": "profiles/pmc_traffic.json — NOT measured by this run",
+                         "algorithmic_bytes_per_launch": ab2,
                          "avg_launch_us": round(c2_us, 3), "pool_shape": {"B": Bc, "T": Tc, "D": Dc, "H": Hc},
                          "workload": "BASELINE config 2: DoubleMHA pooling only, fp32, 8 rotating input buffers, 200 launches back to back",
                          "variant": variant,
@@ -676,11 +726,14 @@ def main():
                         "bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
                         "frac": round(tfs / MFMA_BF16_PEAK_TFS, 4),
                         "traffic": pmc_traffic("embed_conv", args.conv) if args.workload == "embed" else None,
+                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                                          "command, FETCH doubled per the gfx950 note; bench.py cannot profile itself) — NOT measured by this run",
                         "algorithmic_flops_per_launch": avg_fl, "avg_launch_us": round(avg_us, 2),
                         "launches_per_step": len(ctimer.rec) // max(1, nstep_timed),
                         "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": mult,
                         "mfma_executed_tflops": round(tfs * mult, 1), "mfma_executed_frac": round(tfs * mult / MFMA_BF16_PEAK_TFS, 4),
-                        "mfma_util_pmc_percent": mfma_util_pmc()}
+                        "mfma_util_pmc_percent": mfma_util_pmc(),
+                        "mfma_util_source": "profiles/pmc_traffic.json (rocprofv3 --pmc MfmaUtil pass) — NOT measured by this run"}
             wsum = wtimer.summary()
             if wsum is not None:
                 wus, wfl, wtfs = wsum
@@ -745,6 +798,9 @@ def main():
         })
         if companions is not None:
             out["conv_operand_modes"] = companions
+        if world == 1 and args.workload == "embed" and args.conv == "split8" and compute_dtype == torch.float32 and not args.no_companions:
+            torch.cuda.synchronize()
+            out["companion_workloads"] = companion_workloads()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -2,19 +2,19 @@
 # Run on the GPU box (through gpurun): rocprofv3 kernel-trace summaries and PMC traffic passes for bench.py.
 # Raw CSVs land under gpurun_out/prof_$TAG/; tools/summarize_profiles.py turns them into profiles/$TAG_*.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 POOL="python3 bench.py --workload pool --steps 400 --warmup 40 --regions 1 --no-cpu-baseline"
-EMBED="python3 bench.py --steps 6 --warmup 2 --regions 1 --no-cpu-baseline --no-power-probe"
+EMBED="python3 bench.py --steps 6 --warmup 2 --regions 1 --no-cpu-baseline --no-power-probe --no-companions"
 echo "== kernel trace: pool"   && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pool_trace  -- $POOL  > $OUT/pool_trace.log 2>&1  || tail -5 $OUT/pool_trace.log
 echo "== kernel trace: embed"  && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed_trace -- $EMBED > $OUT/embed_trace.log 2>&1 || tail -5 $OUT/embed_trace.log
 echo "== pmc FETCH_SIZE: pool" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pool_fetch -- $POOL > $OUT/pool_fetch.log 2>&1 || tail -5 $OUT/pool_fetch.log
 echo "== pmc WRITE_SIZE: pool" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pool_write -- $POOL > $OUT/pool_write.log 2>&1 || tail -5 $OUT/pool_write.log
 echo "== pmc FETCH_SIZE: embed" && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/embed_fetch -- $EMBED > $OUT/embed_fetch.log 2>&1 || tail -5 $OUT/embed_fetch.log
 echo "== pmc WRITE_SIZE: embed" && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/embed_write -- $EMBED > $OUT/embed_write.log 2>&1 || tail -5 $OUT/embed_write.log
-TRAIN="python3 bench.py --workload train --steps 3 --warmup 2 --regions 1 --no-cpu-baseline"
+TRAIN="python3 bench.py --workload train --steps 3 --warmup 2 --regions 1 --no-cpu-baseline --no-companions"
 echo "== pmc MfmaUtil: embed" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/embed_mfma -- $EMBED > $OUT/embed_mfma.log 2>&1 || tail -5 $OUT/embed_mfma.log
 echo "== pmc MfmaUtil: train" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/train_mfma -- $TRAIN > $OUT/train_mfma.log 2>&1 || tail -5 $OUT/train_mfma.log
 echo "== kernel trace: train" && rocprofv3 --kernel-trace --output-format csv -d $OUT/train_trace -- $TRAIN > $OUT/train_trace.log 2>&1 || tail -5 $OUT/train_trace.log
