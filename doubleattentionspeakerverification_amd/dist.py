@@ -273,12 +273,15 @@ class DataParallelTrainer:
 
     def train_step(self, x, labels, step=0):
         """Forward/backward on this rank's shard.  Every `accum`-th call all-reduces and steps the optimizer.
-        Returns (loss, costh) as device tensors — no host synchronisation."""
+        Returns (loss, costh) as device tensors — no host synchronisation.
+        x: [B,T,80], or a LIST of [T_i,80] utterances of different lengths (a variable-length shard: the model processes every
+        utterance at its own length, model.SpeakerClassifier._utterance_vectors_ragged; every rank must hold the same NUMBER of
+        utterances so that the mean over the global batch stays the mean of the rank means)."""
         self._micro += 1
         last = (self._micro % self.accum == 0)
         if last:
             self.reducer.arm()
-        dev_type = "cuda" if x.is_cuda else "cpu"
+        dev_type = "cuda" if (x[0] if isinstance(x, (list, tuple)) else x).is_cuda else "cpu"
         fused = getattr(self.net, "forward_loss", None) if self.fused_loss else None
         with torch.autocast(dev_type, dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None):
             if fused is not None:

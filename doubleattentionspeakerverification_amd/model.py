@@ -3,6 +3,9 @@
     SpeakerClassifier(parameters: argparse.Namespace, device)
         .getEmbedding(x [B,T,80]) -> [B, embedding_size]                     model.py:52-59
         .forward(x, label=None, step=0) -> (costh, scaled margin logits)     model.py:61-71
+    x may also be a LIST of [T_i, 80] utterances of different lengths (a variable-length minibatch, BASELINE.json north_star):
+    every utterance is then processed at its own length — what the reference can only do one per forward — and the dense tail
+    sees them as one batch (forward, backward and BatchNorm statistics included).
 
 Reads from ``parameters``: front_end, kernel_size, pooling_method, heads_number, mask_prob, embedding_size, num_spkrs,
 scalingFactor, marginFactor, annealing; writes feature_size = 80 (model.py:13).  The sub-module names — front_end,
@@ -81,8 +84,30 @@ class SpeakerClassifier(nn.Module):
             return pool.pool(frames)           # same launch as forward(), alignments skipped
         return pool(self.front_end(x))[0]
 
+    def _utterance_vectors_ragged(self, utterances):
+        """Pooled vectors [B, vector_size] of a minibatch of utterances of DIFFERENT lengths (list of [T_i, 80] tensors), in input
+        order, differentiable.  The reference has no padding and no masks anywhere in the front-end or the pooling, so an
+        utterance must be processed at its own length (train.py:117-133 does one per forward): utterances of EQUAL length share one
+        dense pass (batching.bucket_by_length), and the pooled vectors are put back in order — everything behind the pooling
+        (fc1, fc2, BatchNorm b2 on the statistics of the WHOLE minibatch, the AM-softmax head) then sees one [B, .] batch exactly as
+        if all B utterances had gone through one forward."""
+        from .batching import bucket_by_length
+        lengths = [int(u.shape[0]) for u in utterances]
+        buckets = bucket_by_length(lengths, max_batch=len(utterances))
+        dev = next(self.parameters()).device
+        parts, order = [], []
+        for b in buckets:
+            x = torch.stack([utterances[i] for i in b]).to(dev, non_blocking=True).float()
+            parts.append(self._utterance_vector(x))
+            order += b
+        self.last_ragged_buckets = buckets          # (tests read which utterances shared a pass)
+        inv = torch.empty(len(order), dtype=torch.long)
+        inv[torch.tensor(order)] = torch.arange(len(order))
+        return torch.cat(parts, dim=0).index_select(0, inv.to(dev))
+
     def getEmbedding(self, x):
-        hidden = F.relu(self.fc1(self._utterance_vector(x)))
+        vec = self._utterance_vectors_ragged(x) if isinstance(x, (list, tuple)) else self._utterance_vector(x)
+        hidden = F.relu(self.fc1(vec))
         return self.b2(F.relu(self.fc2(hidden)))
 
     def forward(self, x, label=None, step=0):

@@ -67,9 +67,23 @@ def vgg_forward_decided(x, sd, n_blocks, decisions=None, record=None, prefix="fr
 
 def classifier_train_forward(x, sd, n_blocks, label, keep, m, s, decisions=None, record=None, eps=1e-5):
     """model.py:61-71 in TRAIN mode (BatchNorm1d b2 on batch statistics, model.py:57; b1 / b3 unused, model.py:46,50) with the
-    head mask of poolings.py:39-43 made explicit (`keep` [B,H] bool).  Returns (costh, logits)."""
-    enc = vgg_forward_decided(x, sd, n_blocks, decisions, record)
-    out, _, _ = dmha_opseq(enc, sd["poolingLayer.utteranceAttention.query"], sd["poolingLayer.headsAttention.att"], keep)
+    head mask of poolings.py:39-43 made explicit (`keep` [B,H] bool).  Returns (costh, logits).
+    x: [B,T,F] — or a LIST of [T_i,F] utterances of different lengths: the reference can only run those one utterance per
+    forward through front-end and pooling (no padding, no masks: train.py:117-133); the dense tail then sees the B pooled vectors
+    as ONE batch (`decisions` / `record`: lists, one entry per utterance)."""
+    q, a = sd["poolingLayer.utteranceAttention.query"], sd["poolingLayer.headsAttention.att"]
+    if isinstance(x, (list, tuple)):
+        outs = []
+        for i, u in enumerate(x):
+            rec = {} if record is not None else None
+            enc = vgg_forward_decided(u.unsqueeze(0), sd, n_blocks, None if decisions is None else decisions[i], rec)
+            if record is not None:
+                record.append(rec)
+            outs.append(dmha_opseq(enc, q, a, None if keep is None else keep[i:i + 1])[0])
+        out = torch.cat(outs, dim=0)
+    else:
+        enc = vgg_forward_decided(x, sd, n_blocks, decisions, record)
+        out, _, _ = dmha_opseq(enc, q, a, keep)
     e1 = F.relu(F.linear(out, sd["fc1.weight"], sd["fc1.bias"]))
     e2 = F.relu(F.linear(e1, sd["fc2.weight"], sd["fc2.bias"]))
     e2 = F.batch_norm(e2, None, None, sd["b2.weight"], sd["b2.bias"], True, 0.0, eps)
@@ -85,8 +99,9 @@ def train_step_grads(sd, batches, n_blocks, m, s, decisions=None, dtype=torch.fl
     p = {k: (v.detach().to(dtype).requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
     losses, used = [], []
     for i, (x, label, keep) in enumerate(batches):
-        rec = {}
-        _, logits = classifier_train_forward(x.to(dtype), p, n_blocks, label, keep, m, s,
+        ragged = isinstance(x, (list, tuple))
+        rec = [] if ragged else {}
+        _, logits = classifier_train_forward([u.to(dtype) for u in x] if ragged else x.to(dtype), p, n_blocks, label, keep, m, s,
                                              None if decisions is None else decisions[i], rec)
         loss = F.cross_entropy(logits, label)
         loss.backward()

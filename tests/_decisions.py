@@ -46,17 +46,24 @@ class DecisionCapture:
         self.mp.undo()
         return False
 
-    def decisions(self):
+    def passes(self):
+        """Decisions of every forward pass captured since reset(), in order (a variable-length minibatch is several dense passes)."""
+        n = 3 * self.fe.n_blocks
+        assert len(self.events) % n == 0, len(self.events)
+        return [self.decisions(self.events[k:k + n]) for k in range(0, len(self.events), n)]
+
+    def decisions(self, events=None):
         """{'convXY': bool [B,C,H,W], 'poolX': int64 [B,C,Ho,Wo]} on the CPU, real channels only (the zero-padded network of a
         narrow kernel_size carries pad channels that are identically zero)."""
         fe = self.fe
+        events = self.events if events is None else events
         names = []
         for blk in range(1, fe.n_blocks + 1):
             names += [("conv", "conv%d1" % blk), ("conv", "conv%d2" % blk), ("pool", "pool%d" % blk)]
-        assert [k for k, _ in self.events] == [k for k, _ in names], [k for k, _ in self.events]
+        assert [k for k, _ in events] == [k for k, _ in names], [k for k, _ in events]
         out = {}
         c = None
-        for (kind, name), (_, t) in zip(names, self.events):
+        for (kind, name), (_, t) in zip(names, events):
             if kind == "conv":
                 c = getattr(fe, name).out_channels
                 out[name] = (t[:, :c] > 0).cpu()

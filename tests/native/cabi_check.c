@@ -2,12 +2,15 @@
  * calls the fused pooling through include/dasv_hip.h and checks the result against the plain-C restatement
  * (oracle/dmha_oracle.c, linked in as the checker).  Built and run by tests/test_cabi_native_gpu.py.
  * Shapes: the reference's `DoubleMHA(512, 8)` on [B,T,512] (BASELINE config 2 at a size the scalar checker finishes fast),
- * then one conv3x3+bias+ReLU layer against a naive convolution. */
+ * then one conv3x3+bias+ReLU layer against a naive convolution, then the DEFAULT path of the front-end — range record ->
+ * split8 convolution -> max-pool, and convolution + pool as one launch — and the AM-softmax + cross-entropy head, forward and
+ * backward, each against a plain-C double-precision restatement written right here. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "dasv_hip.h"
 
@@ -104,8 +107,138 @@ int main(void) {
     }
     const int e_shape = dasv_conv3x3_bias_relu_nhwc(0, dcx, whi, wlo, dcb, dcy, cB, cH, cW, 48, co, 1, st);   /* Cin % 64 != 0 */
     printf("conv3x3: max|err| %.3g of scale %.3g; unsupported Cin -> %d\n", e_conv, s_conv, e_shape);
-    const int ok = e_out < 1e-5 && e_al < 1e-5 && e_hw < 1e-5 && e_ctx < 1e-5 && e_null == DASV_E_NULL && e_ws == DASV_E_WORKSPACE &&
-                   e_conv < 2e-5 * s_conv && e_shape == DASV_E_SHAPE;
+    int ok = e_out < 1e-5 && e_al < 1e-5 && e_hw < 1e-5 && e_ctx < 1e-5 && e_null == DASV_E_NULL && e_ws == DASV_E_WORKSPACE &&
+             e_conv < 2e-5 * s_conv && e_shape == DASV_E_SHAPE;
+
+    /* ---- the DEFAULT path of the front-end (ABI v2 / v3): range record -> split8 convolution -> max-pool, and the same
+     * convolution + pool as ONE launch, against the naive double-precision result of the first part (relu'd map `ref`) ---- */
+    double* ref = malloc(nyc * sizeof(double));
+    float amax_x = 0.f;
+    for (size_t i = 0; i < nxc; ++i) amax_x = fmaxf(amax_x, fabsf(cx[i]));
+    for (int b = 0; b < cB; ++b) for (int h = 0; h < cH; ++h) for (int w = 0; w < cW; ++w) for (int n = 0; n < co; ++n) {
+        double acc = cb[n];
+        for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+            const int hh = h + ky - 1, ww = w + kx - 1;
+            if (hh < 0 || hh >= cH || ww < 0 || ww >= cW) continue;
+            const float* xp = cx + (((size_t)b * cH + hh) * cW + ww) * ci;
+            for (int c = 0; c < ci; ++c) acc += (double)xp[c] * cw[((size_t)n * ci + c) * 9 + ky * 3 + kx];
+        }
+        ref[(((size_t)b * cH + h) * cW + w) * co + n] = acc < 0 ? 0 : acc;
+    }
+    uint32_t* drec;                                   /* four range records: x, y, pooled (two-launch), pooled (one launch) */
+    CHECK(hipMalloc((void**)&drec, 8 * sizeof(uint32_t)));
+    CHECK(hipMemsetAsync(drec, 0, 8 * sizeof(uint32_t), st));
+    void *w16, *w8;
+    CHECK(hipMalloc(&w16, dasv_conv3x3_packed_weight_bytes_f16(co, ci)));
+    CHECK(hipMalloc(&w8, dasv_conv3x3_packed_weight_bytes_x8(co, ci)));
+    const int pH = (cH + 1) / 2, pW = (cW + 1) / 2;
+    const size_t npool = (size_t)cB * pH * pW * co;
+    float *dpy, *dpy1, *py = malloc(npool * 4), *py1 = malloc(npool * 4);
+    CHECK(hipMalloc((void**)&dpy, npool * 4)); CHECK(hipMalloc((void**)&dpy1, npool * 4));
+    rc = dasv_range_absmax_f32(dcx, nxc, drec, st);
+    if (!rc) rc = dasv_conv3x3_pack_weights_x8(dcw, dcb, w16, w8, co, ci, st);
+    if (!rc) rc = dasv_conv3x3_bias_relu_x8_nhwc(dcx, 0, drec, w16, w8, dcb, dcy, 0, drec + 2, NULL, 0, cB, cH, cW, ci, co, 1, st);
+    if (!rc) rc = dasv_maxpool2x2_ceil_nhwc(dcy, drec + 2, dpy, drec + 4, cB, cH, cW, co, st);
+    if (!rc) rc = dasv_conv3x3_pool_supported(3, cB, cH, cW, ci, co) ? 0 : DASV_E_SHAPE;
+    if (!rc) rc = dasv_conv3x3_bias_relu_pool_x8_nhwc(dcx, 0, drec, w16, w8, dcb, dpy1, 0, drec + 6, cB, cH, cW, ci, co, 0, st);
+    if (rc) { fprintf(stderr, "split8 path: %s\n", dasv_error_string(rc)); return 4; }
+    uint32_t rec[8];
+    CHECK(hipStreamSynchronize(st));
+    CHECK(hipMemcpy(rec, drec, sizeof(rec), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(cy, dcy, nyc * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(py, dpy, npool * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(py1, dpy1, npool * 4, hipMemcpyDeviceToHost));
+    double e_x8 = 0, e_pool = 0, amax_y = 0;
+    int same = 1;
+    for (size_t i = 0; i < nyc; ++i) { e_x8 = fmax(e_x8, fabs((double)cy[i] - ref[i])); amax_y = fmax(amax_y, (double)cy[i]); }
+    for (int b = 0; b < cB; ++b) for (int h = 0; h < pH; ++h) for (int w = 0; w < pW; ++w) for (int n = 0; n < co; ++n) {
+        double m = 0;                                /* relu'd inputs: the window maximum is >= 0 */
+        for (int dy = 0; dy < 2; ++dy) for (int dx2 = 0; dx2 < 2; ++dx2) {
+            const int hh = 2 * h + dy, ww = 2 * w + dx2;
+            if (hh < cH && ww < cW) m = fmax(m, ref[(((size_t)b * cH + hh) * cW + ww) * co + n]);
+        }
+        const size_t o = (((size_t)b * pH + h) * pW + w) * co + n;
+        e_pool = fmax(e_pool, fabs((double)py1[o] - m));
+        if (py[o] != py1[o]) same = 0;               /* one launch == two launches, bit for bit */
+    }
+    float fx, fy;
+    memcpy(&fx, &rec[0], 4); memcpy(&fy, &rec[2], 4);
+    printf("split8 conv: max|err| %.3g of scale %.3g; records x %.6g (true %.6g) y %.6g (true %.6g) pooled %08x / %08x; conv+pool in one "
+           "launch: max|err| %.3g, identical to two launches: %d\n", e_x8, s_conv, fx, amax_x, fy, amax_y, rec[4], rec[6], e_pool, same);
+    ok = ok && e_x8 < 4e-5 * s_conv && e_pool < 4e-5 * s_conv && same && fx == amax_x && (double)fy == amax_y && rec[4] == rec[2] &&
+         rec[6] == rec[2];
+
+    /* ---- AM-softmax + cross-entropy head (loss.py:37-52, train.py:219): forward and backward against the closed forms in double ---- */
+    {
+        const int aB = 5, aE = 24, aN = 37;
+        const float margin = 0.4f, scale = 30.0f;
+        float *ax = malloc((size_t)aB * aE * 4), *aW = malloc((size_t)aE * aN * 4);
+        long long lab[5] = {3, 36, 0, 17, 3};
+        for (int i = 0; i < aB * aE; ++i) ax[i] = 2.0f * frand(&seed);
+        for (int i = 0; i < aE * aN; ++i) aW[i] = frand(&seed);
+        double xn[5], wn[37], cosr[5 * 37], lossr = 0, dcos[5 * 37];
+        for (int b = 0; b < aB; ++b) { double q2 = 0; for (int e = 0; e < aE; ++e) q2 += (double)ax[b * aE + e] * ax[b * aE + e]; xn[b] = fmax(sqrt(q2), 1e-12); }
+        for (int n = 0; n < aN; ++n) { double q2 = 0; for (int e = 0; e < aE; ++e) q2 += (double)aW[e * aN + n] * aW[e * aN + n]; wn[n] = fmax(sqrt(q2), 1e-12); }
+        for (int b = 0; b < aB; ++b) {
+            double mx = -1e300, se = 0;
+            for (int n = 0; n < aN; ++n) {
+                double d = 0;
+                for (int e = 0; e < aE; ++e) d += (double)ax[b * aE + e] * aW[e * aN + n];
+                cosr[b * aN + n] = d / (xn[b] * wn[n]);
+                const double lg = scale * (cosr[b * aN + n] - (n == lab[b] ? margin : 0.0));
+                mx = fmax(mx, lg);
+            }
+            for (int n = 0; n < aN; ++n) se += exp(scale * (cosr[b * aN + n] - (n == lab[b] ? margin : 0.0)) - mx);
+            for (int n = 0; n < aN; ++n) {
+                const double lg = scale * (cosr[b * aN + n] - (n == lab[b] ? margin : 0.0));
+                dcos[b * aN + n] = scale * (exp(lg - mx) / se - (n == lab[b] ? 1.0 : 0.0)) / aB;
+            }
+            lossr += (mx + log(se)) - scale * (cosr[b * aN + lab[b]] - margin);
+        }
+        lossr /= aB;
+        float *dax, *daW, *dcosth, *dloss, *dlse, *dxinv, *dwinv, *dgx, *dgW;
+        long long* dlab;
+        void* aws;
+        const size_t awb = dasv_amsoftmax_workspace_bytes(aB, aE, aN);
+        CHECK(hipMalloc((void**)&dax, (size_t)aB * aE * 4)); CHECK(hipMalloc((void**)&daW, (size_t)aE * aN * 4));
+        CHECK(hipMalloc((void**)&dcosth, (size_t)aB * aN * 4)); CHECK(hipMalloc((void**)&dloss, 4)); CHECK(hipMalloc((void**)&dlse, aB * 4));
+        CHECK(hipMalloc((void**)&dxinv, aB * 4)); CHECK(hipMalloc((void**)&dwinv, aN * 4)); CHECK(hipMalloc((void**)&dgx, (size_t)aB * aE * 4));
+        CHECK(hipMalloc((void**)&dgW, (size_t)aE * aN * 4)); CHECK(hipMalloc((void**)&dlab, aB * 8)); CHECK(hipMalloc(&aws, awb));
+        CHECK(hipMemcpy(dax, ax, (size_t)aB * aE * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(daW, aW, (size_t)aE * aN * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dlab, lab, aB * 8, hipMemcpyHostToDevice));
+        rc = dasv_amsoftmax_fwd(dax, daW, (const int64_t*)dlab, dcosth, NULL, dloss, dlse, dxinv, dwinv, aws, awb, aB, aE, aN, margin, scale, 0.f, st);
+        if (!rc) rc = dasv_amsoftmax_bwd(dax, daW, (const int64_t*)dlab, dcosth, dlse, dxinv, dwinv, NULL, NULL, NULL, dgx, dgW, aws, awb,
+                                         aB, aE, aN, margin, scale, 0.f, st);
+        if (rc) { fprintf(stderr, "amsoftmax: %s\n", dasv_error_string(rc)); return 4; }
+        float loss_h, *costh_h = malloc((size_t)aB * aN * 4), *gx_h = malloc((size_t)aB * aE * 4), *gW_h = malloc((size_t)aE * aN * 4);
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(&loss_h, dloss, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(costh_h, dcosth, (size_t)aB * aN * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(gx_h, dgx, (size_t)aB * aE * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gW_h, dgW, (size_t)aE * aN * 4, hipMemcpyDeviceToHost));
+        double e_cos = 0, e_gx = 0, s_gx = 0, e_gW = 0, s_gW = 0;
+        for (int i = 0; i < aB * aN; ++i) e_cos = fmax(e_cos, fabs((double)costh_h[i] - cosr[i]));
+        for (int b = 0; b < aB; ++b) {                       /* dx = (d xhat - xhat <xhat, d xhat>) / |x| */
+            double u = 0;
+            for (int n = 0; n < aN; ++n) u += dcos[b * aN + n] * cosr[b * aN + n];
+            for (int e = 0; e < aE; ++e) {
+                double v = 0;
+                for (int n = 0; n < aN; ++n) v += dcos[b * aN + n] * aW[e * aN + n] / wn[n];
+                const double g = (v - ax[b * aE + e] / xn[b] * u) / xn[b];
+                e_gx = fmax(e_gx, fabs((double)gx_h[b * aE + e] - g)); s_gx = fmax(s_gx, fabs(g));
+            }
+        }
+        for (int n = 0; n < aN; ++n) {                       /* dW_n = (d What_n - What_n <What_n, d What_n>) / |W_n| */
+            double t = 0;
+            for (int b = 0; b < aB; ++b) t += dcos[b * aN + n] * cosr[b * aN + n];
+            for (int e = 0; e < aE; ++e) {
+                double v = 0;
+                for (int b = 0; b < aB; ++b) v += dcos[b * aN + n] * ax[b * aE + e] / xn[b];
+                const double g = (v - aW[e * aN + n] / wn[n] * t) / wn[n];
+                e_gW = fmax(e_gW, fabs((double)gW_h[e * aN + n] - g)); s_gW = fmax(s_gW, fabs(g));
+            }
+        }
+        printf("amsoftmax: loss %.7g (ref %.7g), max|err| costh %.3g, gx %.3g of %.3g, gW %.3g of %.3g\n", loss_h, lossr, e_cos, e_gx, s_gx,
+               e_gW, s_gW);
+        ok = ok && fabs(loss_h - lossr) < 2e-5 * fabs(lossr) && e_cos < 2e-6 && e_gx < 1e-4 * s_gx && e_gW < 1e-4 * s_gW;
+    }
     puts(ok ? "CABI_NATIVE_OK" : "CABI_NATIVE_FAIL");
     return ok ? 0 : 1;
 }

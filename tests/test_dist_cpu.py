@@ -212,6 +212,57 @@ def test_a_gradient_that_fires_on_one_rank_only_keeps_the_ranks_in_step(tmp_path
     assert r0["cold"] == r1["cold"]
 
 
+def _ragged_data():
+    rs = np.random.RandomState(17)
+    lens = [5, 9, 5, 3, 7, 9, 4, 6]
+    return [torch.from_numpy(rs.standard_normal((n, 12)).astype(np.float32)) for n in lens], torch.from_numpy(rs.randint(0, 7, size=8))
+
+
+class RaggedTiny(TinyClassifier):
+    """x may be a LIST of [T_i, feat] utterances (a variable-length shard), like SpeakerClassifier.forward."""
+
+    def forward(self, x, label=None, step=0):
+        m = torch.stack([u.mean(dim=0) for u in x]) if isinstance(x, (list, tuple)) else x.mean(dim=1)
+        h = torch.relu(self.fc2(torch.relu(self.fc1(m))))
+        z = self.head(h)
+        return z, 3.0 * z
+
+
+def _worker_ragged(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from doubleattentionspeakerverification_amd.dist import DataParallelTrainer, init_distributed, shard_batch
+    init_distributed("gloo")
+    torch.manual_seed(100)
+    net = RaggedTiny().train()
+    net.bn.eval()
+    tr = DataParallelTrainer(net, lr=1e-2, weight_decay=1e-3, optimizer="SGD", bucket_bytes=256)
+    utts, y = _ragged_data()
+    lo, hi = shard_batch(len(utts), rank, world)
+    tr.train_step(utts[lo:hi], y[lo:hi], step=0)          # a LIST: this rank's utterances, each at its own length
+    torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_variable_length_shards_on_two_gloo_ranks_match_the_full_minibatch(tmp_path):
+    """BASELINE.json north_star: minibatches of variable-length utterances sharded over data-parallel ranks.  Each rank gets a LIST
+    of utterances of different lengths (equal COUNT per rank, so that the global-batch mean of train.py:219's CrossEntropyLoss is
+    the mean of the rank means); one all-reduced step must equal the single-process step on the whole list."""
+    port = _free_port()
+    mp.spawn(_worker_ragged, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    torch.manual_seed(100)
+    net = RaggedTiny().train()
+    net.bn.eval()
+    opt = torch.optim.SGD(list(net.parameters()), lr=1e-2, weight_decay=1e-3)
+    utts, y = _ragged_data()
+    nn.CrossEntropyLoss()(net(utts, label=y)[1], y).backward()
+    opt.step()
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    for k, v in net.state_dict().items():
+        assert torch.equal(r0[k], r1[k]), k
+        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+
+
 class LateBloomerInit:
     @staticmethod
     def extra_weight():

@@ -147,6 +147,63 @@ def test_train_step_matches_reference_adam_and_sgd(monkeypatch):
                     assert np.abs(upd).max() == 0.0, k                # no grad -> untouched
 
 
+def test_variable_length_minibatch_train_step_vs_float64(monkeypatch):
+    """BASELINE.json north_star: "training shards minibatches of variable-length log-mel utterances".  One training step on a
+    minibatch of utterances of DIFFERENT lengths (a list): every utterance goes through front-end and pooling at its own length
+    — no padding, which the reference's mask-free model could not undo (it can only run unequal utterances one per forward,
+    train.py:117-133) — and the dense tail, BatchNorm statistics and the AM-softmax head see ONE batch (model.py:56-71).  Loss and
+    every gradient against the float64 restatement of exactly that (oracle.classifier_train_forward on a list), under the
+    decisions the HIP forward took; the decisions compared with the float64 forward's own and the flips counted."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from doubleattentionspeakerverification_amd.batching import bucket_by_length
+    from _decisions import DecisionCapture
+    p = _params()
+    torch.manual_seed(77)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).train()
+    lens = [40, 57, 40, 33, 57, 64, 40]
+    utts = [torch.from_numpy(rnd(2100 + i, n, 80)) for i, n in enumerate(lens)]
+    lab = torch.tensor([3, 0, 7, 7, 10, 1, 5])
+    keep = torch.rand(len(lens), p.heads_number) > 0.3
+    keep[:, 1] = True
+    buckets = bucket_by_length(lens, max_batch=len(lens))
+    assert sorted(len(b) for b in buckets) == [1, 1, 2, 3]
+    queue = [keep[torch.tensor(b)].to(DEV) for b in buckets]
+    monkeypatch.setattr(net.poolingLayer.headsAttention, "draw_head_keep", lambda batch, heads, device: queue.pop(0))
+    with DecisionCapture(monkeypatch, net.front_end) as cap:
+        loss, _ = net.forward_loss([u.to(DEV) for u in utts], lab.to(DEV), 0)
+        loss.backward()
+        per_pass = cap.passes()
+    assert not queue and net.last_ragged_buckets == buckets and len(per_pass) == len(buckets)
+    decs = [None] * len(lens)
+    for b, d in zip(buckets, per_pass):
+        for j, i in enumerate(b):
+            decs[i] = {k: v[j:j + 1] for k, v in d.items()}
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    l_own, _, own = oracle.train_step_grads(sd, [(utts, lab, keep)], 4, p.marginFactor, p.scalingFactor)
+    flips = sum(sum(oracle.count_flips(own[0][i], decs[i], 4).values()) for i in range(len(lens)))
+    l64, g64, _ = oracle.train_step_grads(sd, [(utts, lab, keep)], 4, p.marginFactor, p.scalingFactor, decisions=[decs])
+    print("variable-length minibatch: loss %.6f (float64 %.6f), %d forward decisions differ from the float64 forward's" % (float(loss.detach()), l64[0], flips))
+    assert abs(float(loss) - l64[0]) < 2e-5 * abs(l64[0]) and flips <= 40
+    for n, q in net.named_parameters():
+        if n.startswith(("b1.", "b3.")):
+            assert q.grad is None
+            continue
+        ref = g64[n].numpy()
+        # (1-D gradients behind the train-mode BatchNorm — fc2.bias above all — are exactly zero in exact arithmetic: what an fp32
+        # run leaves there is the cancellation residue of O(10) terms, multiples of 2^-12 at this loss scale; absolute bound)
+        atol = 4e-3 if ref.ndim == 1 else 1e-4 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(q.grad.cpu().numpy(), ref, rtol=2e-3, atol=atol, err_msg=n)
+    # the same list through the data-parallel trainer (one rank): a step is taken, the loss is the same
+    from doubleattentionspeakerverification_amd.dist import DataParallelTrainer
+    queue.extend(keep[torch.tensor(b)].to(DEV) for b in buckets)
+    monkeypatch.setattr(net.poolingLayer.headsAttention, "draw_head_keep", lambda batch, heads, device: queue.pop(0))   # (undone with the capture)
+    net.zero_grad(set_to_none=True)
+    tr = DataParallelTrainer(net, lr=1e-3, weight_decay=0.0, optimizer="SGD")
+    before = net.fc1.weight.detach().clone()
+    loss2, _ = tr.train_step([u.to(DEV) for u in utts], lab.to(DEV), step=0)
+    assert abs(float(loss2) - float(loss)) < 1e-5 * abs(float(loss)) and float((net.fc1.weight - before).abs().max()) > 0
+
+
 def test_default_config_embedding_vs_oracle_and_bf16_error():
     """Reference default model (VGG4L/1024, 32 heads, emb 400) on a small batch: fp32 within 1e-3 relative of
     the CPU oracle; the bf16-autocast path's error is reported, not hidden."""
