@@ -78,10 +78,11 @@ class _VGG(nn.Module):
         self.half_activations = True
         # inference chains: convX2 + ReLU + the block's 2x2 ceil max-pool as ONE launch (conv.conv3x3_x8 / conv3x3_f16, pool=True).
         # `fuse_pool_layers`: the (block, mode) pairs it is switched on for — where the same-process A/B on [64,300,80] says it pays
-        # (tools/_diag/pool_fuse_ab.py, profiles/r04_pool_fusion_ab.txt: split8 block 1 -1.3 %, block 2 -0.5 ... -1.4 %, both -2.4 %
-        # of the front-end's time; blocks 3 / 4 lose 0.4 / 2.4 % — tiles of whole row pairs leave 6-8 % of a 256-pixel tile idle and
-        # push their 760 / 1,500 workgroups into one more round of the 256 CUs, which costs more than their small pools save; with
-        # fp16 operands the convolutions are twice as fast and only block 2 breaks even).  Every (block, mode) pair runs and is tested.
+        # (tools/_diag/pool_fuse_ab.py, profiles/r04_pool_fusion_ab.txt, r04_patch_tiles_ab.txt).  split8: block 1 runs on 16 x 16
+        # pixel PATCH tiles (csrc/conv3x3.hip GEOM = 1), which hold whole pooling windows and waste nothing: -5.6 % of the
+        # front-end's time; block 2 (row-pair tiles, 240 of 256 pixel rows used) another -0.7 %; blocks 3 / 4 lose 0.4 / 2.4 % — their
+        # row-pair tiles push 760 / 1,500 workgroups into one more round of the 256 CUs, which costs more than their small pools
+        # save.  With fp16 operands the convolutions are twice as fast and only block 2 breaks even.  Every pair runs and is tested.
         self.fuse_pool = True
         self.pool_tile = 0          # tile shape of the fused launches (0: automatic; measurements force 160 / 192 / 256)
         self.fuse_pool_layers = {(1, "split8"), (2, "split8"), (2, "fp16")}

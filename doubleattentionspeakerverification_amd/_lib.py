@@ -94,6 +94,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "dasv_debug_set_tuning": (None, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_debug_read_floor": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "dasv_debug_conv_patch_tiles": (None, [c_int]),
 }
 
 DTYPE_CODES = {"float32": 0, "bfloat16": 1, "float16": 2}

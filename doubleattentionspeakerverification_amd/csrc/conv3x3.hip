@@ -435,8 +435,17 @@ constexpr int WBM = 256, WMAXROWS = WBM + 2 * 80 + 2, WACH = (WMAXROWS * 16 + 51
 // WM = waves along the pixels (x NWN along the 128 output channels).  WM = 2, NWN = 4, IB = 5: eight waves of 80 pixels x 32 channels
 // = 160-pixel tiles — a whole ROW PAIR of an 80-column map (and 2 / 4 / 8 pairs of the 40- / 20- / 10-column ones), the tile shape of
 // the fused max-pool epilogue (ConvParams::pool) that wastes no pixel rows of the matrix work.
-template <int PREC, bool DBUF, bool C1, int NWN, int IB = 4, int WM = 4>
+// GEOM = 1 (PATCH tiles, maps whose width is a multiple of 16 — the 80-column first block): a tile is a 16 x 16 pixel patch of ONE
+// image instead of 256 raster pixels.  Its window is the 18 x 18 patch around it — 324 rows instead of 256 + 2 W + 2 = 418 on an
+// 80-column map — which leaves room for both weight-tile buffers beside a 256-pixel tile (the raster form needs 192-pixel tiles
+// there), and every 2 x 2 pooling window lies inside the tile, so the fused max-pool wastes no pixel rows.  A 16-pixel MFMA block is
+// one patch row: the A fragment of tap (dy, dx) for block y is window rows (y + 1 + dy) * 18 + 1 + dx ... + 15, blocks 18 rows
+// apart; the LDS swizzle key is the window COLUMN (the same for every block, so block addresses stay base + constant).
+template <int PREC, bool DBUF, bool C1, int NWN, int IB = 4, int WM = 4, int GEOM = 0>
 __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const ConvParams p) {
+    static_assert(GEOM == 0 || (WM == 4 && IB == 4 && NWN == 2 && DBUF && !C1), "patch tiles: the pipelined 4 x 2 wave layout");
+    constexpr int PW = 18;                  // patch window pitch (GEOM = 1)
+    constexpr int ABLK = GEOM ? PW * 128 : 2048;      // bytes between the A fragments of consecutive 16-pixel blocks of a wave
     static_assert((WM == 4 && (IB == 4 || (IB == 3 && NWN == 2 && !C1))) || (WM == 2 && NWN == 4 && IB == 5 && !C1 && DBUF),
                   "256-pixel tiles; 192-pixel tiles: 8-wave layout, activations from memory; 160-pixel tiles: 2 x 4 waves, pipelined");
     constexpr int TBM = 16 * IB * WM;   // pixels per workgroup tile (WM waves along the pixels x IB blocks of 16)
@@ -453,7 +462,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int W = p.W, H = p.H, Cin = p.Cin;
-    const int wrows = TBM + 2 * W + 2;
+    const int wrows = GEOM ? PW * PW : TBM + 2 * W + 2;
     char* Ahi = smem;
     char* Alo = Ahi + (size_t)wrows * 128;   // X8: rows of { e4m3(v) x 64 | e4m3(r * 2^12) x 64 }
     char* Bbase = Alo + (TWO ? (size_t)wrows * 128 : 0);   // [DBUF ? 2 : 1] x { B_hi 16 KB | B_lo 16 KB }
@@ -492,7 +501,15 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     int m0 = mt * TBM, mend = p.M;
     const int n0 = nt * CBN;
     int pu0 = 0, pu1 = 0;          // fused pool: the tile's units [pu0, pu1)
-    if (p.pool) {
+    int gb = 0, gh0 = 0, gw0 = 0;  // patch tiles: image, first row and first column of the 16 x 16 patch
+    if constexpr (GEOM == 1) {
+        const int txn = W >> 4, per_img = ((H + 15) >> 4) * txn;
+        gb = mt / per_img;
+        const int r = mt - gb * per_img, ty = r / txn;
+        gh0 = ty << 4;
+        gw0 = (r - ty * txn) << 4;
+        m0 = (gb * H + gh0) * W + gw0;
+    } else if (p.pool) {
         pu0 = mt * p.pool_units;
         pu1 = min(pu0 + p.pool_units, p.B * p.pool_U);
         const int b0 = pu0 / p.pool_U, b1 = pu1 / p.pool_U;
@@ -505,6 +522,19 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     unsigned amask[IB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
+        if constexpr (GEOM == 1) {
+            const int h_ = gh0 + wm * IB + i, w_ = gw0 + frow;      // block i of this wave = patch row wm * IB + i
+            unsigned mask = 0;
+            if (h_ < H) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int hh = h_ + tap / 3 - 1, ww = w_ + tap % 3 - 1;
+                    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << tap;
+                }
+            }
+            amask[i] = mask;
+            continue;
+        }
         const int m = m0 + wm * (16 * IB) + i * 16 + frow;
         unsigned mask = 0;
         if (m < mend) {
@@ -593,10 +623,36 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     // per chunk across the tap loops, which have none to spare.
     const int nfull = wrows / RSTEP;
     const bool wtail = wr0 < wrows - nfull * RSTEP;
+    // patch tiles: window row wr = py * 18 + px <-> image pixel (gh0 - 1 + py, gw0 - 1 + px), clamped into the image (a tap whose
+    // source pixel lies outside the image never reads its window row: border mask -> zero row); (wr * 3641) >> 16 == wr / 18 below 600
+    auto patch_pix = [&](int wr, int& px) {
+        const int py = (wr * 3641) >> 16;
+        px = wr - PW * py;
+        const int gh = min(max(gh0 - 1 + py, 0), H - 1), gw = min(max(gw0 - 1 + px, 0), W - 1);
+        return (gb * H + gh) * W + gw;
+    };
     auto load_window = [&](const float* xs) {
         int pb = (int)pix0;
         asm volatile("" : "+v"(pb));
         const float* xc = xs - pix0 * Cin;          // = x + c0 + wach * 4
+        if constexpr (GEOM == 1) {
+            int w0r = wr0;
+            asm volatile("" : "+v"(w0r));           // (per slab, not hoisted: see below)
+            const bool half = PREC == PREC_F16 && p.x_packed == 2;      // fp16 tensor: a pixel's slab is 128 bytes = chunks 0-7
+            const char* xb = reinterpret_cast<const char*>(p.x) + (half ? ((size_t)((int)(xc - p.x) - wach * 4) * 2 + (size_t)(wach & 7) * 16) : 0);
+#pragma unroll
+            for (int k = 0; k < WACHN; ++k) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < nfull || (k == nfull && wtail)) {
+                    int px;
+                    const int pix = patch_pix(w0r + RSTEP * k, px);
+                    if (half) { if (wach < 8) v = *reinterpret_cast<const f32x4*>(xb + (size_t)pix * Cin * 2); }
+                    else v = *reinterpret_cast<const f32x4*>(xc + (size_t)pix * Cin);
+                }
+                ra[k] = v;
+            }
+            return;
+        }
         if constexpr (PREC == PREC_F16) {
             if (p.x_packed == 2) {
                 // half-precision x: a pixel's 64-channel slab is 128 bytes = chunks 0-7; the staging is a copy (threads with
@@ -626,6 +682,38 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
         }
     };
     auto store_window = [&]() {
+        if constexpr (GEOM == 1) {
+            // LDS row = window row, 16-byte slot XORed with the window COLUMN (px & 7): the 16 lanes of a fragment read consecutive
+            // columns, and every block of a wave reads the same columns
+            int w0r = wr0;
+            asm volatile("" : "+v"(w0r));           // (recomputed per slab: hoisted, the eleven row offsets would live across the tap loops)
+#pragma unroll
+            for (int k = 0; k < WACHN; ++k) {
+                if (k < nfull || (k == nfull && wtail)) {
+                    const int wr = w0r + RSTEP * k, py = (wr * 3641) >> 16, key = (wr - PW * py) & 7;
+                    char* rowh = Ahi + wr * 128;
+                    char* rowl = Alo + wr * 128;
+                    if (X8 && p.x_packed) {
+                        *reinterpret_cast<f32x4*>((wach < 8 ? rowh : rowl) + (((wach & 7) ^ key) << 4)) = ra[k];
+                    } else if (PREC == PREC_F16 && p.x_packed == 2) {
+                        if (wach < 8) *reinterpret_cast<f32x4*>(rowh + ((wach ^ key) << 4)) = ra[k];
+                    } else {
+                        uint32_t h0, l0, h1, l1;
+                        if constexpr (X8) {
+                            cvt4_x8(ra[k], sx, h0, h1, l0, l1);
+                            *reinterpret_cast<uint32_t*>(rowl + (((wach >> 2) ^ key) << 4) + (wach & 3) * 4) = l0;
+                            *reinterpret_cast<uint32_t*>(rowl + (((4 + (wach >> 2)) ^ key) << 4) + (wach & 3) * 4) = l1;
+                        } else {
+                            cvt2<PREC>(ra[k][0], ra[k][1], h0, l0);
+                            cvt2<PREC>(ra[k][2], ra[k][3], h1, l1);
+                            if (SPLIT) *reinterpret_cast<uint2*>(rowl + (((wach >> 1) ^ key) << 4) + (wach & 1) * 8) = make_uint2(l0, l1);
+                        }
+                        *reinterpret_cast<uint2*>(rowh + (((wach >> 1) ^ key) << 4) + (wach & 1) * 8) = make_uint2(h0, h1);
+                    }
+                }
+            }
+            return;
+        }
         if (X8 && p.x_packed) {
             // the producer already made the planes: chunks 0-7 of a pixel's slab are the fp16 row, 8-11 / 12-15 the e4m3 rows.
             // (Measured and dropped, round 2: the packed window by LDS-DMA, issued EARLY — behind the last tap's MFMAs, once
@@ -806,6 +894,16 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
         for (int j = 0; j < JT; ++j) wsc[j] = sc[(size_t)(n0 + wn * NPW + j * 16 + frow) * 4 + (fq & 1)];
     }
 
+    // byte offset (inside a window plane) of this lane's A fragment of tap `tap`, 16-byte slot `slot`, for its wave's block 0
+    auto a_off = [&](int tap, int slot) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        if constexpr (GEOM == 1) {
+            const int col = 1 + dx + frow;
+            return ((wm * IB + 1 + dy) * PW + col) * 128 + ((slot ^ (col & 7)) << 4);
+        } else {
+            return lds_off(wm * (16 * IB) + frow + (W + 1) + dy * W + dx, slot);
+        }
+    };
     f32x4 acc[IB][JT];
 #pragma unroll
     for (int i = 0; i < IB; ++i)
@@ -839,13 +937,12 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             }
         };
         auto read_a = [&](Frags& f, int tap, int kk) {
-            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
-            const int o = lds_off(arow, kk * 4 + fq);
+            const int o = a_off(tap, kk * 4 + fq);
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
-                f.ah[i] = *reinterpret_cast<const bf16x8*>(ok ? Ahi + o + i * 2048 : Zrow);
-                if constexpr (SPLIT) f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * 2048 : Zrow);
+                f.ah[i] = *reinterpret_cast<const bf16x8*>(ok ? Ahi + o + i * ABLK : Zrow);
+                if constexpr (SPLIT) f.al[i] = *reinterpret_cast<const bf16x8*>(ok ? Alo + o + i * ABLK : Zrow);
             }
         };
         auto mma_rows = [&](const Frags& f, int i0, int i1) {
@@ -924,15 +1021,13 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             for (int j = 0; j < JT; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + (kk ? bo1 : bo0) + j * 2048);
         };
         auto read_f16_a = [&](bf16x8 (&ah)[IB], int tap, int kk) {
-            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
-            const int o = lds_off(arow, kk * 4 + fq);
+            const int o = a_off(tap, kk * 4 + fq);
 #pragma unroll
             for (int i = 0; i < IB; ++i)
-                ah[i] = *reinterpret_cast<const bf16x8*>(((amask[i] >> tap) & 1u) ? Ahi + o + i * 2048 : Zrow);
+                ah[i] = *reinterpret_cast<const bf16x8*>(((amask[i] >> tap) & 1u) ? Ahi + o + i * ABLK : Zrow);
         };
         auto read_e4m3 = [&](const char* Bhi, int tap) {
-            const int arow = wm * (16 * IB) + frow + (W + 1) + (tap / 3 - 1) * W + (tap % 3 - 1);
-            const int o0 = lds_off(arow, s1), o1 = lds_off(arow, s2);
+            const int o0 = a_off(tap, s1), o1 = a_off(tap, s2);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
                 wl[j] = *reinterpret_cast<const u32x4*>(Bhi + bq0 + j * 2048);
@@ -941,8 +1036,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const bool ok = (amask[i] >> tap) & 1u;
-                xl[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o0 + i * 2048 : Zrow);
-                xh[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o1 + i * 2048 : Zrow);
+                xl[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o0 + i * ABLK : Zrow);
+                xh[i] = *reinterpret_cast<const u32x4*>(ok ? Alo + o1 + i * ABLK : Zrow);
             }
         };
         auto mma_f16 = [&](const bf16x8 (&b)[JT], const bf16x8 (&a)[IB]) {
@@ -1229,7 +1324,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 for (int i = 0; i < IB; ++i) {
                     f32x4 v = (SCALED ? acc[i][j] * sc : acc[i][j]) + bv;
                     if (p.relu) v = relu4(v);
-                    if (m0 + wm * (16 * IB) + i * 16 + (lane & 15) < mend) note4(v);
+                    if (GEOM == 1 ? gh0 + wm * IB + i < H : m0 + wm * (16 * IB) + i * 16 + (lane & 15) < mend) note4(v);
                     char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
                     if (p.pool) {
                         // fused max-pool: the image holds the fp32 values; the output form is applied to the pooled values below
@@ -1268,7 +1363,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 // applies, scaled by the exponent of THIS layer's output bound since the true maximum is not known before the last
                 // tile has finished) or fp16.  The full-resolution map never reaches memory.
                 const int Wo = (W + 1) >> 1, Ho = (H + 1) >> 1, U = p.pool_U;
-                const int npool = (pu1 - pu0) * Wo;
+                const int npool = GEOM == 1 ? 64 : (pu1 - pu0) * Wo;     // patch tiles: the 8 x 8 pooled patch
                 const int col = tid & 31;
                 auto mx4 = [](f32x4 a, f32x4 v) {
 #pragma unroll
@@ -1276,16 +1371,30 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     return a;
                 };
                 for (int q = tid >> 5; q < npool; q += NT / 32) {
-                    const int j = q / Wo, c = q - j * Wo;
-                    const int u = pu0 + j, b = u / U, k = u - b * U;
-                    const int lp = (b * H + 2 * k) * W + 2 * c - m0;          // the window's first pixel inside the tile
-                    const bool c1 = 2 * c + 1 < W, r1 = 2 * k + 1 < H;
+                    int lp, rowp = W;             // first pixel of the window inside the tile's image; pixels per tile row
+                    bool c1, r1;
+                    long long op;
+                    if constexpr (GEOM == 1) {
+                        const int r = q >> 3, c = q & 7;                     // pooled pixel (r, c) of the patch
+                        if (gh0 + 2 * r >= H) continue;                      // (a patch that hangs over the bottom of the image)
+                        lp = 32 * r + 2 * c;
+                        rowp = 16;
+                        c1 = true;                                           // W % 16 == 0: the window's second column exists
+                        r1 = gh0 + 2 * r + 1 < H;
+                        op = ((long long)gb * Ho + (gh0 >> 1) + r) * Wo + (gw0 >> 1) + c;
+                    } else {
+                        const int j = q / Wo, c = q - j * Wo;
+                        const int u = pu0 + j, b = u / U, k = u - b * U;
+                        lp = (b * H + 2 * k) * W + 2 * c - m0;
+                        c1 = 2 * c + 1 < W;
+                        r1 = 2 * k + 1 < H;
+                        op = ((long long)b * Ho + k) * Wo + c;
+                    }
                     const char* src = smem + lp * OP + col * 16;
                     f32x4 v = *reinterpret_cast<const f32x4*>(src);
                     if (c1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + OP));
-                    if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + W * OP));
-                    if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (W + 1) * OP));
-                    const long long op = ((long long)b * Ho + k) * Wo + c;
+                    if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + rowp * OP));
+                    if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (rowp + 1) * OP));
                     if (PREC == PREC_F16 && p.y_packed == 2) {
                         const f32x4 qv = v * sy;
                         const f16x2_t a = __builtin_convertvector(f32x2_t{qv[0], qv[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{qv[2], qv[3]}, f16x2_t);
@@ -1306,7 +1415,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 #pragma unroll
                 for (int k = 0; k < TBM / 32; ++k) {
                     const int pix = (tid >> 4) + 32 * k;
-                    const int m = m0 + pix;
+                    int m = m0 + pix;
+                    if constexpr (GEOM == 1) m = gh0 + (pix >> 4) < H ? (gb * H + gh0 + (pix >> 4)) * W + gw0 + (pix & 15) : p.M;
                     if (m < p.M)
                         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.y) + ((size_t)m * p.Cout + n0) * 2 + col16 * 16) =
                             *reinterpret_cast<const f32x4*>(smem + pix * OP + col16 * 16);
@@ -1318,7 +1428,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 #pragma unroll
             for (int k = 0; k < TBM / 16; ++k) {
                 const int pix = (tid >> 5) + 16 * k;
-                const int m = m0 + pix;
+                int m = m0 + pix;
+                if constexpr (GEOM == 1) m = gh0 + (pix >> 4) < H ? (gb * H + gh0 + (pix >> 4)) * W + gw0 + (pix & 15) : p.M;
                 if (m < p.M)
                     *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
             }
@@ -1402,6 +1513,12 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __rest
     }
     if (y_rec != nullptr) range_note_block(y_rec, amax_u, &s_amax);
 }
+
+#ifdef DASV_DEBUG
+static int g_patch_tiles = 1;            // developer build only (dasv_debug_conv_patch_tiles): A/B of the patch-tile geometry
+#else
+static constexpr int g_patch_tiles = 1;
+#endif
 
 // split-K factor of the window kernel: when the map has too few output tiles to fill the chip (small batches), the
 // channel slabs of a tile are divided over several workgroups
@@ -1527,6 +1644,32 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         // both tile buffers (stride 32 KB also for the one-plane modes) whenever they fit: the launch then runs the pipelined loops
         // (round 1 measured the double buffer alone as a loss for bf16 operands — with the un-pipelined loop)
         const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
+        // patch tiles (GEOM = 1): maps whose width is a multiple of 16 and whose raster window would be larger than the 18 x 18
+        // patch window (80 / 64 / 48 columns; the 80-column first block in this model) — pipelined fp16 / split8 launches without
+        // masks, column sums, ragged borders or split-K
+        // (measured, tools/_diag/pool_fuse_ab.py, profiles/r04_pool_fusion_ab.txt: split8 on [64,300,80] -1.7 % of the front-end's time
+        // for the plain layer and -5.6 % with the fused pool; with fp16 operands, whose raster form already has 256-pixel tiles there,
+        // the patch form is 4.5 % SLOWER — more address arithmetic per staged chunk — so it is a split8 geometry)
+        const bool patch = mode == 3 && W % 16 == 0 && W >= 48 && mask == nullptr && colsum == nullptr && mel == nullptr &&
+                           row_span == nullptr && S == 1 && pool_tile == 0 && dasv::g_patch_tiles;
+        if (patch) {
+            p.mtiles = B * ((H + 15) / 16) * (W / 16);
+            p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
+            if (pool) { p.pool = 1; p.pool_units = 0; p.pool_U = (H + 1) / 2; }
+            size_t ldsp = (size_t)324 * 128 * (two ? 2 : 1) + 65536 + 128;
+            if (ldsp < (size_t)256 * 528) ldsp = (size_t)256 * 528;
+            const dim3 gridp((unsigned)(p.tiles_per_xcd * 8));
+#define DASV_LAUNCH_PATCH(SP)                                                                                       \
+            do {                                                                                                    \
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dasv::conv3x3_window_kernel<SP, true, false, 2, 4, 4, 1>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);          \
+                if (e != hipSuccess) return (int)e;                                                                 \
+                hipLaunchKernelGGL((dasv::conv3x3_window_kernel<SP, true, false, 2, 4, 4, 1>), gridp, dim3(512), ldsp, s, p); \
+            } while (0)
+            DASV_LAUNCH_PATCH(3);
+#undef DASV_LAUNCH_PATCH
+            return (int)hipGetLastError();
+        }
         bool t160 = false;
         if (pool) {
             // tiles of whole row pairs (the pooled tile is formed in the coalescing epilogue's LDS image: pipelined launches only).
@@ -1669,6 +1812,10 @@ int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_
                           static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, 1, stream, nullptr, x_f16 ? 2 : 0,
                           y_f16 ? 2 : 0, x_range, y_range, 1, tile_pixels);
 }
+
+#ifdef DASV_DEBUG
+void dasv_debug_conv_patch_tiles(int on) { dasv::g_patch_tiles = on; }
+#endif
 
 #if DASV_CONV_STAMPS
 int dasv_debug_conv_stamps(unsigned long long* out) {

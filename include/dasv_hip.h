@@ -426,6 +426,9 @@ void dasv_debug_set_tuning(int waves_per_group, int waves_per_head, int lds_pad_
  * adds per-wave sums into scratch[0..2047] (>= 2048 floats, caller-zeroed).  bench.py times it beside the fused pooling
  * kernel: no kernel that streams x once can be faster than this on the same buffers. */
 int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stream_t stream);
+/* A/B aid: 0 = the convolutions never take the patch-tile geometry (16 x 16 pixel tiles on maps whose width is a multiple of 16);
+ * 1 (default) = automatic. */
+void dasv_debug_conv_patch_tiles(int on);
 #endif /* DASV_DEBUG */
 
 #ifdef __cplusplus
