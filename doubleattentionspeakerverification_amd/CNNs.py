@@ -157,8 +157,9 @@ class _VGG(nn.Module):
         return packed
 
     def _forward_map_packed(self, x):
-        """conv11 -> PACKED -> conv12 -> fp32 -> pool -> PACKED -> convX1 -> PACKED -> convX2 -> fp32 -> pool -> PACKED ... : bit-identical
-        to the fp32 chain (same conversion arithmetic, done by the producer instead of by every consumer workgroup).  A packed
+        """conv11 -> PACKED -> conv12 (+ pool) -> PACKED -> convX1 -> PACKED -> convX2 (+ pool) -> PACKED ... : the fp32 chain's values to
+        2e-5 (same conversion arithmetic, done by the producer instead of by every consumer workgroup; a packed OUTPUT is scaled by
+        the layer's bound where the consumer of an fp32 tensor uses its measured maximum).  A packed
         input saves a layer 5-7 %.  The pools write packed for free (0.185 vs 0.183 ms), conv11 for +0.02 ms; a convolution's
         epilogue only because it goes through LDS (coalescing epilogue): with 8- and 4-byte stores straight to memory the packed
         output cost the producing layer 18 % (tools/_diag/packed_pieces.py)."""

@@ -54,8 +54,12 @@ __device__ unsigned long long dasv_conv_stamps[128];
 // slots 0-63: the 100 MHz clock; 64-127: the shader-cycle counter at the same points (their ratio is the clock the CU held)
 #define DASV_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) { dasv_conv_stamps[k] = __builtin_amdgcn_s_memrealtime(); \
                                                                                   dasv_conv_stamps[64 + (k)] = __builtin_readcyclecounter(); } } while (0)
+// per-slab stamps: slots 2 ... 59 (the first 14 slabs; slots 60-63 are the epilogue's, 64+ the cycle counters — a 16-slab layer
+// used to write its last slabs' stamps over them: the conv42 row of profiles/r03_summary.md)
+#define DASV_STAMP_SLAB(k) do { if ((k) < 58) DASV_STAMP(k); } while (0)
 #else
 #define DASV_STAMP(k) do { } while (0)
+#define DASV_STAMP_SLAB(k) do { } while (0)
 #endif
 #ifndef DASV_CONV_SCHED
 #define DASV_CONV_SCHED 1   // reads-first scheduling hint (tools/conv_diag.py A/B)
@@ -1061,16 +1065,16 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
         DASV_STAMP(1);
         for (int sl = sl_lo; sl < nslab; ++sl) {
             const int c0 = sl * CBK;
-            DASV_STAMP(2 + 4 * (sl - sl_lo));
+            DASV_STAMP_SLAB(2 + 4 * (sl - sl_lo));
             load_window(xrun + c0);
             if (sl > sl_lo) __syncthreads();   // every wave is done reading the previous slab's window
-            DASV_STAMP(3 + 4 * (sl - sl_lo));
+            DASV_STAMP_SLAB(3 + 4 * (sl - sl_lo));
             store_window();
             {
                 char* Bcur = Bbase + ((it & 1) ? 32768 : 0);
                 dma_drain();
                 __syncthreads();
-                DASV_STAMP(4 + 4 * (sl - sl_lo));
+                DASV_STAMP_SLAB(4 + 4 * (sl - sl_lo));
                 dma_b(Bbase + ((it & 1) ? 0 : 32768), 1, c0);
                 read_f16_b(bh0, Bcur, 0);
                 read_f16_a(ah0, 0, 0);
@@ -1129,7 +1133,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 }
                 mma_e4m3(2, IB);
             }
-            DASV_STAMP(5 + 4 * (sl - sl_lo));
+            DASV_STAMP_SLAB(5 + 4 * (sl - sl_lo));
         }
     } else
     for (int sl = sl_lo; sl < nslab; ++sl) {
