@@ -102,18 +102,21 @@ class _VGG(nn.Module):
                 and self._mode() is not None and conv.weight.dtype == torch.float32
                 and _hipconv.supported(conv.in_channels, conv.out_channels))
 
-    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None, x_rec=None, y_rec=None):
+    def _conv_relu(self, name, h, grad_premasked=False, mask_input_grad=False, link_in=None, link_out=None, x_rec=None, y_rec=None,
+                   span=None, borders=None):
         """x_rec / y_rec: range records of h and of the result (split8 mode; None: h is measured by a pass over it).  Returns
-        (result, record of the result or None)."""
+        (result, record of the result or None).  span / borders: the border tables of a ragged training batch (forward_map)."""
         conv = getattr(self, name)
         if not self._use_hip_conv(name, h):
+            if span is not None:
+                raise RuntimeError("ragged training batches run on the hand-written kernels only")
             return F.relu(conv(h)), None
         key = (name, h.device.index)   # nn.DataParallel replicas share this dict: one packed copy per device
         packed = self._packed.get(key)
         if packed is None:
             packed = self._packed[key] = _hipconv.PackedConvWeights()
         return _hipconv.conv3x3_bias_relu(h, conv.weight, conv.bias, packed, self._mode(), grad_premasked, mask_input_grad,
-                                          link_in, link_out, x_rec, y_rec), y_rec
+                                          link_in, link_out, x_rec, y_rec, span, borders), y_rec
 
     def _c1_padded(self):
         """conv11's weight / bias zero-padded to the channel count the hand-written kernels want from the first layer: a multiple
@@ -244,13 +247,31 @@ class _VGG(nn.Module):
         # [B,C,T',F'] -> [B,T',C*F'] with feature = c*F' + f
         return h.permute(0, 2, 1, 3).reshape(h.size(0), h.size(2), h.size(1) * h.size(3))
 
-    def forward_map(self, paddedInputTensor):
+    def ragged_training_ok(self, fdim=80):
+        """A ragged TRAINING batch (forward_map(..., tables=...)) runs when every layer is on the hand-written kernels in the split8
+        mode with channel counts the kernels take without padding."""
+        if self.conv_mode != "split8" or torch.is_autocast_enabled() or fdim > 80 or self.conv11.out_channels % 64 != 0 \
+                or self.conv11.out_channels > 1024:
+            return False
+        return all(_hipconv.exact(c.in_channels, c.out_channels) and c.weight.dtype == torch.float32
+                   for blk in range(1, self.n_blocks + 1) for c in (getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk))
+                   if c is not self.conv11)
+
+    def forward_map(self, paddedInputTensor, tables=None):
         """The front-end up to, not including, the final transpose/contiguous/view (CNNs.py:49-50 / 88-89): the
         [B, C, T', F'] map (channels_last memory on the HIP path).  The pooling kernels can read it in place
-        (poolings.nhwc_frames_supported), which is how SpeakerClassifier uses it."""
+        (poolings.nhwc_frames_supported), which is how SpeakerClassifier uses it.
+        tables (training on a RAGGED batch, ragged.train_tables): paddedInputTensor is [1, sum T_i, F] — utterances of different
+        lengths stacked along time — and tables = (spans, pools, borders) per block; forward and backward then treat every
+        utterance as its own image (the reference can only do that one utterance per forward)."""
         B, T, Fdim = paddedInputTensor.shape
         hip = self._hip_front(paddedInputTensor)
         grad = torch.is_grad_enabled()
+        spans = pools = borders = [None] * self.n_blocks
+        if tables is not None:
+            if not (hip and grad and B == 1 and self.ragged_training_ok(Fdim)):
+                raise RuntimeError("ragged training batches need the split8 mode on the GPU, gradients enabled and exact channel counts")
+            spans, pools, borders = tables
         if hip and not grad and self.packed_activations and self._mode() == "split8" and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_packed(paddedInputTensor)
         if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
@@ -277,7 +298,7 @@ class _VGG(nn.Module):
                 rh = next(recs) if x8 else None
                 # conv12 runs with mask_input_grad (below) whenever it is on the HIP kernel: conv11's ReLU mask is then applied there
                 h = _hipconv.conv3x3_c1_bias_relu_autograd(paddedInputTensor, *self._c1_padded(), rh,
-                                                           grad_premasked=self._use_hip_conv("conv12", paddedInputTensor))
+                                                           grad_premasked=self._use_hip_conv("conv12", paddedInputTensor), span=spans[0])
             else:
                 rh = next(recs) if x8 else None
                 w11, b11 = self._c1_padded()
@@ -295,15 +316,16 @@ class _VGG(nn.Module):
             hip2 = self._use_hip_conv(n2, h)
             pool_hip = hip and h.dtype == torch.float32
             l1, l2 = ({}, {}) if grad else (None, None)
+            sp, bd = spans[blk - 1], borders[blk - 1]
             if not (hip and blk == 1):
-                h, rh = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1, x_rec=rh, y_rec=next(recs) if x8 else None)
+                h, rh = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1, x_rec=rh, y_rec=next(recs) if x8 else None, span=sp, borders=bd)
             if not (fused_first and blk == 1):
                 h, rh = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True, link_in=l2,
                                         link_out=None if (hip and blk == 1) else l1,   # conv11's kernel sums its own bias gradient
-                                        x_rec=rh, y_rec=next(recs) if x8 else None)
+                                        x_rec=rh, y_rec=next(recs) if x8 else None, span=sp, borders=bd)
             if pool_hip and h.dtype == torch.float32:
                 ry = next(recs) if (x8 and rh is not None) else None
-                h = (_hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2, x_rec=rh, y_rec=ry) if grad
+                h = (_hipconv.maxpool2x2_ceil_autograd(h, relu_input=hip2, link_out=l2, x_rec=rh, y_rec=ry, pool_src=pools[blk - 1]) if grad
                      else _hipconv.maxpool2x2_ceil(h, x_rec=rh, y_rec=ry))
                 rh = ry
             else:

@@ -70,6 +70,11 @@ SIGNATURES = {
     "dasv_ragged_tables": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dasv_maxpool2x2_ceil_idx_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_bwd_idx_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_idx_ragged_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_bwd_idx_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_bwd_colsum_rows_ragged": (c_int, [c_int, c_int, c_int]),
+    "dasv_conv3x3_masked_ragged_x8_nhwc": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bwd_ragged_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_c1_bwd_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

@@ -160,15 +160,39 @@ def _rec_of(t):
     return tagged[0]
 
 
-def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None):
+def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None, span=None):
     """colsum (with mask): a dict that receives 'gb' = per-channel sums of the masked output (fixed-order partial sums
     from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel.
-    x_rec / y_rec (split8): range records of x (made here by a pass over x when the caller has none) and of y (optional)."""
+    x_rec / y_rec (split8): range records of x (made here by a pass over x when the caller has none) and of y (optional).
+    span (split8): x is a RAGGED batch — utterances of different lengths stacked along H in one image [1, C, rows, W] — and span
+    its border table (ragged.ragged_tables): taps never cross from one utterance into the next."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if mode == "split8" and x_rec is None:
         x_rec = range_of(x)
+    if span is not None:
+        if mode != "split8" or B != 1 or W > 80:
+            raise RuntimeError("ragged batches in training run in the split8 mode (one stacked image, maps up to 80 columns)")
+        with torch.cuda.device(x.device):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if mask is not None:
+                rows = lib.dasv_conv3x3_colsum_rows(1, H, W) if colsum is not None else 0
+                part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
+                rc = lib.dasv_conv3x3_masked_ragged_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
+                                                            y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
+                                                            None if part is None else part.data_ptr(), span.data_ptr(), H, W, cin, cout, stream)
+                if part is not None and rc == 0:
+                    colsum["gb"] = part.sum(dim=0)
+            else:
+                nws = lib.dasv_conv3x3_workspace_bytes(1, H, W, cin, cout)
+                ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+                rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(x.data_ptr(), 0, x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                               None if bias is None else bias.data_ptr(), y.data_ptr(), 0,
+                                                               None if y_rec is None else y_rec.data_ptr(), span.data_ptr(),
+                                                               None if ws is None else ws.data_ptr(), nws, H, W, cin, cout, relu, stream)
+        _lib.check(rc, "dasv_conv3x3_*_ragged_x8_nhwc")
+        return y
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if mode == "split8" and mask is not None:
@@ -210,11 +234,28 @@ def supported_wgrad(cin, cout, width=1, pixels=0):
     return cin % 64 == 0 and cout % 64 == 0 and width <= 80 and pixels * max(cin, cout) * 4 < 0xffffffff
 
 
-def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None):
+def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
     """Weight gradient [Cout,Cin,3,3] of conv3x3 (stride 1, pad 1) from x [B,Cin,H,W] and g [B,Cout,H,W]
     (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip).
     mode "split8": fp16 products + block-scaled e4m3 cross terms; x_rec / g_rec are the operands' range records (an upper bound
-    of max |v| is enough; measured here with one pass over the tensor when None)."""
+    of max |v| is enough; measured here with one pass over the tensor when None).
+    borders (ragged batch: x / g are utterances stacked along H in one image, B == 1): int64 tensor of the first rows of the
+    utterances 1 ... n-1.  The launch on the stacked image also multiplies across every border — g of an utterance's first row with x of
+    the previous utterance's last row (taps ky = 0) and g of a last row with x of the next first row (ky = 2); exactly those products
+    are computed a second time from 2-row images {last row | first row} and subtracted."""
+    if borders is not None and borders.numel() > 0:
+        if x.shape[0] != 1:
+            raise RuntimeError("a ragged batch is one stacked image")
+        tall = conv3x3_wgrad(x, g, mode, x_rec, g_rec)
+        x3, g3 = x.permute(0, 2, 3, 1)[0], g.permute(0, 2, 3, 1)[0]              # [rows, W, C] views of the channels_last memory
+        xl, xf, gl, gf = x3[borders - 1], x3[borders], g3[borders - 1], g3[borders]
+        zx, zg = torch.zeros_like(xl), torch.zeros_like(gl)
+        xb = torch.cat([torch.stack([xl, zx], dim=1), torch.stack([zx, xf], dim=1)]).permute(0, 3, 1, 2)     # [2 nb, C, 2, W] channels_last
+        gb = torch.cat([torch.stack([zg, gf], dim=1), torch.stack([gl, zg], dim=1)]).permute(0, 3, 1, 2)
+        if mode == "split8":           # the same scales as the stacked launch (the records bound these rows too)
+            x_rec = range_of(x) if x_rec is None else x_rec
+            g_rec = range_of(g) if g_rec is None else g_rec
+        return tall - conv3x3_wgrad(xb, gb, mode, x_rec, g_rec)
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = g.shape[1]
@@ -242,7 +283,7 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None):
 
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec):
+    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span=None, borders=None):
         # x carries cin_x >= Cin channels (a multiple of 64; the surplus is zero) and y gets padded_channels(Cout): the layer runs
         # as its zero-padded form (see `supported`)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -251,7 +292,8 @@ class _ConvReLUFn(torch.autograd.Function):
         bias_k = packed.bias if (cin_x, cout_p) != (cin, cout) and bias is not None else bias
         if mode == "split8" and x_rec is None:
             x_rec = range_of(x)
-        y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec)
+        y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec, span=span)
+        ctx.span, ctx.borders = span, borders           # ragged batch (one stacked image): border tables of this level
         ctx.save_for_backward(x, weight, y)
         ctx.x_rec = x_rec           # (split8) the weight gradient scales x by the same record
         ctx.has_bias = bias is not None
@@ -295,11 +337,11 @@ class _ConvReLUFn(torch.autograd.Function):
                 # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
                 # backward is applied in this kernel's epilogue
                 gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
-                             colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec)
+                             colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span)
                 if gx_rec is not None:
                     _attach_rec(gx, gx_rec)
             else:
-                gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec)[:, :cin_x].contiguous(memory_format=torch.channels_last)
+                gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec, span=ctx.span)[:, :cin_x].contiguous(memory_format=torch.channels_last)
                 if ctx.mask_input_grad:
                     gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
             want_x = False
@@ -308,7 +350,7 @@ class _ConvReLUFn(torch.autograd.Function):
             wmode = WGRAD_MODE[ctx.mode]
             # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
             gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
-                               g_rec=_rec_of(gy) if wmode == "split8" else None)
+                               g_rec=_rec_of(gy) if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None)
             if padded:
                 gw = gw[:cout, :cin].contiguous()
             want_w = False
@@ -319,6 +361,8 @@ class _ConvReLUFn(torch.autograd.Function):
                     gb = g.sum(dim=(0, 2, 3))
                 gb = gb[:cout] if padded else gb
                 want_b = False
+        if (want_x or want_w or want_b) and ctx.span is not None:
+            raise RuntimeError("ragged training batch: a gradient fell outside the hand-written kernels' limits (operands beyond 4 GB?)")
         if want_x or want_w or want_b:
             # (maps wider than 80 columns / operands beyond 4 GB only: the weight-gradient kernel's limits)
             wfull = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin_x - cin, 0, cout_p - cout)) if padded else weight
@@ -329,11 +373,11 @@ class _ConvReLUFn(torch.autograd.Function):
                 gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
             gw = (gw2[:cout, :cin].contiguous() if padded else gw2) if want_w else gw
             gb = (gb2[:cout] if padded else gb2) if want_b else gb
-        return gx, gw, gb, None, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
-                      link_in=None, link_out=None, x_rec=None, y_rec=None):
+                      link_in=None, link_out=None, x_rec=None, y_rec=None, span=None, borders=None):
     """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
 
     Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
@@ -346,6 +390,9 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     also leaves its per-channel sums (= the producer layer's bias gradient) in `link_out["gb"]`; the layer that receives
     that gradient passes the same dict as `link_in` and skips its own reduction pass.
     x_rec / y_rec (mode "split8"): range records (new_ranges) of x — measured here with one pass over x when None — and of y.
+    span / borders (training on a RAGGED batch, split8): x is [1, C, rows, W] — utterances of different lengths stacked along H — with
+    its border table (ragged.ragged_tables) and the first rows of utterances 1 ... n-1 (int64): forward, data gradient and weight
+    gradient then treat every utterance as its own image.
     Channel counts that are not multiples of (64, 128): x may carry more channels than the layer has inputs (zeros), and the
     result carries padded_channels(Cout) channels, the surplus identically zero (see `supported`); slice when needed."""
     if not x.is_cuda:
@@ -363,7 +410,7 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         mode = "split"   # the fp16 + e4m3 form exists in the window kernel (maps up to 80 columns) only
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
-    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec)
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
@@ -560,20 +607,29 @@ class _MaxPoolFn(torch.autograd.Function):
     bytes and the incoming gradient only — the full-resolution map is not saved and not read again."""
 
     @staticmethod
-    def forward(ctx, x, relu_input, link_out, x_rec, y_rec):
+    def forward(ctx, x, relu_input, link_out, x_rec, y_rec, pool_src=None):
         lib = _lib.load()
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         B, C, H, W = x.shape
-        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        # pool_src (ragged batch: one stacked image): [rows_out, 2] = {first input row, has-second-row} per output row
+        Ho, Wo = ((H + 1) // 2 if pool_src is None else int(pool_src.shape[0])), (W + 1) // 2
         y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        xr = None if x_rec is None else x_rec.data_ptr()
+        yr = None if (x_rec is None or y_rec is None) else y_rec.data_ptr()
         with torch.cuda.device(x.device):
-            rc = lib.dasv_maxpool2x2_ceil_idx_nhwc(x.data_ptr(), None if x_rec is None else x_rec.data_ptr(), y.data_ptr(),
-                                                   None if (x_rec is None or y_rec is None) else y_rec.data_ptr(), idx.data_ptr(),
-                                                   B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            if pool_src is None:
+                rc = lib.dasv_maxpool2x2_ceil_idx_nhwc(x.data_ptr(), xr, y.data_ptr(), yr, idx.data_ptr(), B, H, W, C, st)
+            else:
+                if B != 1:
+                    raise RuntimeError("a ragged batch is one stacked image")
+                rc = lib.dasv_maxpool2x2_ceil_idx_ragged_nhwc(x.data_ptr(), xr, y.data_ptr(), yr, idx.data_ptr(), pool_src.data_ptr(),
+                                                              H, Ho, W, C, st)
         _lib.check(rc, "dasv_maxpool2x2_ceil_idx_nhwc")
         ctx.save_for_backward(idx)
+        ctx.pool_src = pool_src
         ctx.xshape = (B, C, H, W)
         ctx.relu_input = relu_input
         ctx.link_out = link_out
@@ -588,34 +644,58 @@ class _MaxPoolFn(torch.autograd.Function):
         gx = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
         with torch.cuda.device(gy.device):
             stream = torch.cuda.current_stream(gy.device).cuda_stream
-            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if (ctx.relu_input and ctx.link_out is not None) else 0
+            want_sum = ctx.relu_input and ctx.link_out is not None
+            if ctx.pool_src is None:
+                rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if want_sum else 0
+            else:
+                rows = lib.dasv_maxpool2x2_bwd_colsum_rows_ragged(int(ctx.pool_src.shape[0]), W, C) if want_sum else 0
             part = torch.empty((rows, C), dtype=torch.float32, device=gy.device) if rows > 0 else None
-            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), gx.data_ptr(), None if part is None else part.data_ptr(),
-                                                       int(bool(ctx.relu_input)), B, H, W, C, stream)
+            if ctx.pool_src is None:
+                rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), gx.data_ptr(), None if part is None else part.data_ptr(),
+                                                           int(bool(ctx.relu_input)), B, H, W, C, stream)
+            else:
+                rc = lib.dasv_maxpool2x2_ceil_bwd_idx_ragged_nhwc(idx.data_ptr(), gy.data_ptr(), gx.data_ptr(),
+                                                                  None if part is None else part.data_ptr(), int(bool(ctx.relu_input)),
+                                                                  ctx.pool_src.data_ptr(), H, int(ctx.pool_src.shape[0]), W, C, stream)
             if part is not None and rc == 0:
                 ctx.link_out["gb"] = part.sum(dim=0)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
         rec = _rec_of(gy)
         if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)
             _attach_rec(gx, rec)
-        return gx, None, None, None, None
+        return gx, None, None, None, None, None
 
 
-def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None, x_rec=None, y_rec=None):
+def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None, x_rec=None, y_rec=None, pool_src=None):
     """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors.
 
     relu_input=True: x is the output of a conv3x3_bias_relu(..., grad_premasked=True) call and nothing else consumes it —
     the backward then also passes the gradient through that ReLU (one fused pass instead of two), and leaves that conv's
     bias gradient in `link_out["gb"]` (see conv3x3_bias_relu)."""
-    return _MaxPoolFn.apply(x, relu_input, link_out, x_rec, y_rec)
+    return _MaxPoolFn.apply(x, relu_input, link_out, x_rec, y_rec, pool_src)
 
 
 class _Conv11ReLUFn(torch.autograd.Function):
     """relu(conv2d(x[:,None], w, b, padding 1)) for x [B,H,W] (no gradient w.r.t. x: x is the input feature map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, y_rec, grad_premasked=False):
-        y = conv3x3_c1_bias_relu(x, weight, bias, y_rec=y_rec)
+    def forward(ctx, x, weight, bias, y_rec, grad_premasked=False, span=None):
+        if span is None:
+            y = conv3x3_c1_bias_relu(x, weight, bias, y_rec=y_rec)
+        else:      # ragged batch: x [1, rows, W], utterances stacked along the rows, borders from `span`
+            lib = _lib.load()
+            x = x.contiguous()
+            B, H, W = x.shape
+            if B != 1:
+                raise RuntimeError("a ragged batch is one stacked image")
+            y = torch.empty((1, weight.shape[0], H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+            with torch.cuda.device(x.device):
+                rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                               None if bias is None else bias.detach().data_ptr(), y.data_ptr(),
+                                                               None if y_rec is None else y_rec.data_ptr(), span.data_ptr(), H, W,
+                                                               weight.shape[0], 1, torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
+        ctx.span = span
         ctx.save_for_backward(x.contiguous(), y)
         ctx.grad_premasked = grad_premasked
         ctx.has_bias = bias is not None
@@ -635,15 +715,20 @@ class _Conv11ReLUFn(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
             # (grad_premasked: the consumer's data-gradient kernel multiplied gy by (y > 0) already — y is not read again)
-            rc = lib.dasv_conv3x3_c1_bwd_nhwc(x.data_ptr(), None if ctx.grad_premasked else y.data_ptr(), gy.data_ptr(), gw.data_ptr(),
-                                              None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes, B, H, W, cout,
-                                              torch.cuda.current_stream(x.device).cuda_stream)
+            if ctx.span is None:
+                rc = lib.dasv_conv3x3_c1_bwd_nhwc(x.data_ptr(), None if ctx.grad_premasked else y.data_ptr(), gy.data_ptr(), gw.data_ptr(),
+                                                  None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes, B, H, W, cout,
+                                                  torch.cuda.current_stream(x.device).cuda_stream)
+            else:
+                rc = lib.dasv_conv3x3_c1_bwd_ragged_nhwc(x.data_ptr(), None if ctx.grad_premasked else y.data_ptr(), gy.data_ptr(),
+                                                         gw.data_ptr(), None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes,
+                                                         ctx.span.data_ptr(), H, W, cout, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_c1_bwd_nhwc")
-        return None, gw, gb, None, None
+        return None, gw, gb, None, None, None
 
 
-def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None, grad_premasked=False):
+def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None, grad_premasked=False, span=None):
     """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad.
     grad_premasked: the one consumer of the result applies this layer's ReLU mask to the gradient it sends back (a following
     conv3x3_bias_relu(..., mask_input_grad=True)), so the backward reads that gradient only."""
-    return _Conv11ReLUFn.apply(x, weight, bias, y_rec, grad_premasked)
+    return _Conv11ReLUFn.apply(x, weight, bias, y_rec, grad_premasked, span)

@@ -1878,6 +1878,15 @@ int dasv_conv3x3_masked_x8_nhwc(const float* x, const uint32_t* x_range, const v
                           Cin, Cout, 0, stream, nullptr, 0, 0, x_range, y_range);
 }
 
+int dasv_conv3x3_masked_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                       const float* mask, float* y, uint32_t* y_range, float* colsum_partial, const int* row_span,
+                                       int rows, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask == nullptr || row_span == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, mask, colsum_partial, y, nullptr, 0, 1, rows, W,
+                          Cin, Cout, 0, stream, row_span, 0, 0, x_range, y_range);
+}
+
 int dasv_conv3x3_colsum_rows(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0 || W > 80) return 0;
     return (int)(((long long)B * H * W + dasv::WBM - 1) / dasv::WBM);

@@ -239,7 +239,8 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
                                                                   long long nvec, int relu_mask, float* __restrict__ colsum,
-                                                                  const uint8_t* __restrict__ idx) {
+                                                                  const uint8_t* __restrict__ idx, const int* __restrict__ pool_src) {
+    // pool_src (ragged batch: B == 1, H = total input rows, Ho = total output rows): {first input row, has-second-row} per output row
     // idx (optional): the forward pass's {arg-max | 4 if maximum > 0} bytes — x is then not read (x may be null)
     // colsum (optional): [gridDim.x][C] per-channel sums of the gradient this workgroup scattered (= the bias gradient of
     // the conv whose ReLU output was pooled).  Needs (C/4) | 256 so that a thread keeps the same four channels throughout.
@@ -251,9 +252,12 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         const long long op = i / cq;
         const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
         const long long b = op / ((long long)Wo * Ho);
-        const int h0 = 2 * ho, w0 = 2 * wo;
+        int h0 = 2 * ho;
+        const int w0 = 2 * wo;
+        bool hh = h0 + 1 < H;
+        if (pool_src != nullptr) { h0 = pool_src[2 * ho]; hh = pool_src[2 * ho + 1] != 0; }
         const size_t base = (((size_t)b * H + h0) * W + w0) * C + q * 4;
-        const bool hw = w0 + 1 < W, hh = h0 + 1 < H;
+        const bool hw = w0 + 1 < W;
         const size_t o1 = base + C, o2 = base + (size_t)W * C, o3 = o2 + C;
         f4 g = *reinterpret_cast<const f4*>(gy + (size_t)op * C + q * 4);
         int arg[4] = {0, 0, 0, 0};
@@ -312,7 +316,10 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
 // part: [nblk][Cout][10]
 __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ gy, float* __restrict__ part,
-                                                             int H, int W, int Cout, long long npix, int pix_per_block) {
+                                                             int H, int W, int Cout, long long npix, int pix_per_block,
+                                                             const int* __restrict__ row_span) {
+    // row_span (ragged batch: one tall image of H = total rows): {first row, one past the last row} of the utterance that owns each
+    // row — a tap's source row must lie inside it
     extern __shared__ float red[];   // [ppb][Cout][10]
     const int quads = Cout >> 2, ppb = blockDim.x / quads;
     const int q = threadIdx.x % quads, pl = threadIdx.x / quads;
@@ -358,10 +365,12 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __rest
                 const long long pu = pix + (long long)u * ppb;
                 if (pu < p1) {
                     float in[9];
+                    int hlo = 0, hhi = H;
+                    if (row_span != nullptr) { hlo = row_span[2 * h_]; hhi = row_span[2 * h_ + 1]; }
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-                        in[t] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? x[pu + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                        in[t] = (hh >= hlo && hh < hhi && (unsigned)ww < (unsigned)W) ? x[pu + (t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -633,16 +642,24 @@ static long long maxpool_bwd_blocks(int B, int H, int W, int C) {
     return blocks > 256 * 32 ? 256 * 32 : blocks;
 }
 
+static long long maxpool_bwd_blocks_out(long long out_rows, int W, int C) {
+    const long long nvec = out_rows * ((W + 1) / 2) * (C / 4);
+    const long long blocks = (nvec + 255) / 256;
+    return blocks > 256 * 32 ? 256 * 32 : blocks;
+}
+
 static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
-                              float* colsum, dasv_stream_t stream, const uint8_t* idx = nullptr) {
+                              float* colsum, dasv_stream_t stream, const uint8_t* idx = nullptr, const int* pool_src = nullptr,
+                              int rows_out = 0) {
     if (colsum != nullptr && (C / 4 > 256 || 256 % (C / 4) != 0)) return DASV_E_SHAPE;
     if ((x == nullptr && idx == nullptr) || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    if (pool_src != nullptr && (B != 1 || rows_out <= 0)) return DASV_E_SHAPE;
+    const int Ho = pool_src != nullptr ? rows_out : (H + 1) / 2, Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
-    const long long blocks = maxpool_bwd_blocks(B, H, W, C);
+    const long long blocks = pool_src != nullptr ? maxpool_bwd_blocks_out(rows_out, W, C) : maxpool_bwd_blocks(B, H, W, C);
     hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
-                       C, Ho, Wo, nvec, relu_mask, colsum, idx);
+                       C, Ho, Wo, nvec, relu_mask, colsum, idx, pool_src);
     return (int)hipGetLastError();
 }
 
@@ -669,6 +686,25 @@ int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float
     return maxpool_bwd_launch(nullptr, gy, gx, B, H, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx);
 }
 
+/* the training pool and its backward over a ragged batch (pool_src as in dasv_maxpool2x2_ceil_ragged_nhwc): utterances of different
+ * lengths in ONE training minibatch (BASELINE.json north_star; the reference draws one length per batch, train.py:205-207) */
+int dasv_maxpool2x2_ceil_idx_ragged_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, uint8_t* idx,
+                                         const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr || pool_src == nullptr) return DASV_E_NULL;
+    return pool_launch(x, y, pool_src, 1, rows_in, rows_out, W, C, 0, x_range, y_range, stream, 0, idx);
+}
+
+int dasv_maxpool2x2_ceil_bwd_idx_ragged_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask,
+                                             const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr || pool_src == nullptr) return DASV_E_NULL;
+    return maxpool_bwd_launch(nullptr, gy, gx, 1, rows_in, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx, pool_src, rows_out);
+}
+
+int dasv_maxpool2x2_bwd_colsum_rows_ragged(int rows_out, int W, int C) {
+    if (rows_out <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || C / 4 > 256 || 256 % (C / 4) != 0) return 0;
+    return (int)maxpool_bwd_blocks_out(rows_out, W, C);
+}
+
 int dasv_maxpool2x2_bwd_colsum_rows(int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || C / 4 > 256 || 256 % (C / 4) != 0) return 0;
     return (int)maxpool_bwd_blocks(B, H, W, C);
@@ -679,8 +715,22 @@ size_t dasv_conv3x3_c1_bwd_workspace_bytes(int B, int H, int W, int Cout) {
     return (size_t)2048 * Cout * 10 * sizeof(float);
 }
 
+static int c1_bwd_launch(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream, const int* row_span);
+
 int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream) {
+    return c1_bwd_launch(x, y, gy, gw, gb, workspace, workspace_bytes, B, H, W, Cout, stream, nullptr);
+}
+
+int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                                    size_t workspace_bytes, const int* row_span, int rows, int W, int Cout, dasv_stream_t stream) {
+    if (row_span == nullptr) return DASV_E_NULL;
+    return c1_bwd_launch(x, y, gy, gw, gb, workspace, workspace_bytes, 1, rows, W, Cout, stream, row_span);
+}
+
+static int c1_bwd_launch(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream, const int* row_span) {
     if (x == nullptr || gy == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;      // y may be NULL: gy pre-masked
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     if (workspace_bytes < dasv_conv3x3_c1_bwd_workspace_bytes(B, H, W, Cout)) return DASV_E_WORKSPACE;
@@ -694,7 +744,7 @@ int dasv_conv3x3_c1_bwd_nhwc(const float* x, const float* y, const float* gy, fl
     hipStream_t s = (hipStream_t)stream;
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_kernel, dim3((unsigned)nblk), dim3(256), lds, s, x, y, gy, part, H, W, Cout, npix,
-                       pix_per_block);
+                       pix_per_block, row_span);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 * 16 + 255) / 256)), dim3(256), 0, s, part, gw, gb, nblk, Cout);

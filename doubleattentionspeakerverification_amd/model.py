@@ -73,6 +73,9 @@ class SpeakerClassifier(nn.Module):
             self.add_module(name, layer)
         self.predictionLayer = _loss.AMSoftmax(emb, parameters.num_spkrs, s=parameters.scalingFactor,
                                                m=parameters.marginFactor, annealing=parameters.annealing)
+        # variable-length TRAINING minibatches (a list of utterances): "stacked" = one set of launches with border tables where the
+        # front-end's kernels take them (split8, exact channel counts), else / "buckets" = one dense pass per distinct length
+        self.ragged_training = "stacked"
 
     def _utterance_vector(self, x):
         pool = self.poolingLayer
@@ -93,6 +96,14 @@ class SpeakerClassifier(nn.Module):
         if all B utterances had gone through one forward."""
         from .batching import bucket_by_length
         lengths = [int(u.shape[0]) for u in utterances]
+        dev0 = next(self.parameters()).device
+        if (self.ragged_training == "stacked" and self.training and torch.is_grad_enabled() and dev0.type == "cuda"
+                and len(set(lengths)) > 1 and self.front_end.ragged_training_ok()):
+            # ONE set of launches for the whole minibatch, forward and backward: the utterances stacked along time, borders from
+            # tables (ragged.utterance_vectors_ragged_train)
+            from .ragged import utterance_vectors_ragged_train
+            self.last_ragged_buckets = None
+            return utterance_vectors_ragged_train(self, utterances)
         buckets = bucket_by_length(lengths, max_batch=len(utterances))
         dev = next(self.parameters()).device
         parts, order = [], []

@@ -18,7 +18,8 @@ from . import _lib
 from . import conv as _conv
 from . import poolings as _pool
 
-__all__ = ["embed_ragged", "embed_ragged_batches", "ragged_tables", "front_end_ragged", "plan_ragged_groups"]
+__all__ = ["embed_ragged", "embed_ragged_batches", "ragged_tables", "front_end_ragged", "plan_ragged_groups", "train_tables",
+           "utterance_vectors_ragged_train"]
 
 
 def _upload_int64(values, device):
@@ -332,6 +333,40 @@ def embed_ragged(net, utterances, mode=None):
         raise RuntimeError("unsupported pooling layer %r" % type(pool).__name__)
     hidden = torch.relu(net.fc1(vec))
     return net.b2(torch.relu(net.fc2(hidden)))
+
+
+def train_tables(lengths, levels, device):
+    """Border tables of a ragged TRAINING batch: (spans, pools, borders) per block for CNNs.forward_map(..., tables=...) —
+    ragged_tables' spans / pools plus, per level, the first rows of utterances 1 ... n-1 (int64; what conv.conv3x3_wgrad subtracts
+    the cross-border products at) — and the output lengths and the (owner, row) index of every output frame."""
+    import numpy as np
+    spans, pools, lens, fin = ragged_tables(lengths, levels, device, with_index=True)
+    borders = [_upload_int64([int(v) for v in np.cumsum(lens[l])[:-1]], device) for l in range(levels)]
+    return (spans, pools, borders), list(lens[-1]), fin
+
+
+def utterance_vectors_ragged_train(net, utterances):
+    """Pooled vectors [B, vector_size] of a TRAINING minibatch of utterances of different lengths in ONE set of launches, forward
+    and backward (BASELINE.json north_star; the reference can only run unequal utterances one per forward, train.py:117-133): the
+    utterances are stacked along time, the front-end's kernels take the borders from tables in both directions (the weight gradient
+    subtracts the cross-border products, conv.conv3x3_wgrad), and the pooling runs on a zero-padded [B, T'max, D] copy of the (small)
+    front-end output with per-utterance lengths.  Differentiable; same values as one utterance per forward."""
+    import numpy as np
+    front = net.front_end
+    dev = next(net.parameters()).device
+    x = torch.cat([u.to(dev, non_blocking=True).float() for u in utterances], dim=0).unsqueeze(0)       # [1, sum T_i, 80]
+    tables, tl, fin = train_tables([int(u.shape[0]) for u in utterances], front.n_blocks, dev)
+    h = front.forward_map(x, tables=tables)                                     # [1, C, rows', F'] (channels_last)
+    frames = h[0].permute(1, 0, 2).reshape(h.shape[2], h.shape[1] * h.shape[3])   # feature = c * F' + f (CNNs.py:88-89)
+    B, tmax = len(tl), max(tl)
+    padded = frames.new_zeros((B, tmax, frames.shape[1])).index_put((fin[0], fin[1]), frames)
+    lengths = _upload_np(np.asarray(tl, dtype=np.int32), dev)
+    pool = net.poolingLayer
+    if isinstance(pool, _pool.DoubleMHA):
+        return pool.pool(padded, lengths=lengths)
+    if isinstance(pool, (_pool.MultiHeadAttention, _pool.Attention)):
+        return pool(padded, lengths=lengths)[0]
+    raise RuntimeError("unsupported pooling layer %r" % type(pool).__name__)
 
 
 def plan_ragged_groups(lengths, max_frames=64 * 300, rank=0, world=1):

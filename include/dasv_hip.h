@@ -275,6 +275,22 @@ int dasv_maxpool2x2_ceil_idx_nhwc(const float* x, const uint32_t* x_range, float
                                   int W, int C, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask, int B,
                                       int H, int W, int C, dasv_stream_t stream);
+/* The TRAINING forms over a ragged batch — utterances of different lengths in one minibatch (BASELINE.json north_star; the reference
+ * draws one window length per batch, train.py:205-207, and can only run unequal utterances one per forward): the pool with its index
+ * bytes and its backward, the masked split8 data gradient, conv11's backward — the dense launches above with the border tables.  The
+ * weight gradient of a ragged batch is dasv_conv3x3_wgrad_x8_nhwc on the stacked image (B = 1, H = rows) MINUS the same launch on the
+ * 2-row images {last row of utterance i, first row of utterance i+1} that carry exactly the products across the borders
+ * (doubleattentionspeakerverification_amd/conv.py, conv3x3_wgrad(..., span_borders=...)). */
+int dasv_maxpool2x2_ceil_idx_ragged_nhwc(const float* x, const uint32_t* x_range, float* y, uint32_t* y_range, uint8_t* idx,
+                                         const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_bwd_idx_ragged_nhwc(const uint8_t* idx, const float* gy, float* gx, float* colsum_partial, int relu_mask,
+                                             const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
+int dasv_maxpool2x2_bwd_colsum_rows_ragged(int rows_out, int W, int C);
+int dasv_conv3x3_masked_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                       const float* mask, float* y, uint32_t* y_range, float* colsum_partial, const int* row_span,
+                                       int rows, int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
+                                    size_t workspace_bytes, const int* row_span, int rows, int W, int Cout, dasv_stream_t stream);
 /* Border tables of a ragged batch (utterances of different lengths stacked along time: what the reference does one utterance per
  * forward, train.py:117-133), made on the device in ONE launch from the B utterance lengths (lengths_dev int32 on the device;
  * lengths_host the same values on the host: the sizes below are host arithmetic).  rows_l = sum_b ceil(len_b / 2^l).

@@ -52,6 +52,35 @@ class DecisionCapture:
         assert len(self.events) % n == 0, len(self.events)
         return [self.decisions(self.events[k:k + n]) for k in range(0, len(self.events), n)]
 
+    def decisions_stacked(self, lengths):
+        """The captured pass ran on a RAGGED batch (utterances of `lengths` frames stacked along time in one image): the decisions
+        per utterance, as oracle.classifier_train_forward takes them for a list."""
+        fe = self.fe
+        whole = self.decisions()
+        lens, per_level = [int(n) for n in lengths], []
+        for _ in range(fe.n_blocks):
+            per_level.append(lens)
+            lens = [(n + 1) // 2 for n in lens]
+        out = []
+        ev = {}
+        names = []
+        for blk in range(1, fe.n_blocks + 1):
+            names += ["conv%d1" % blk, "conv%d2" % blk, "pool%d" % blk]
+        for name, (_, t) in zip(names, self.events):
+            ev[name] = t
+        for i in range(len(lengths)):
+            d = {}
+            for blk in range(1, fe.n_blocks + 1):
+                r0 = sum(per_level[blk - 1][:i])
+                r1 = r0 + per_level[blk - 1][i]
+                for name in ("conv%d1" % blk, "conv%d2" % blk):
+                    d[name] = whole[name][:, :, r0:r1, :]
+                c = getattr(fe, "conv%d2" % blk).out_channels
+                d["pool%d" % blk] = F.max_pool2d(ev["pool%d" % blk][:, :c, r0:r1, :].contiguous(), 2, stride=2, ceil_mode=True,
+                                                 return_indices=True)[1].cpu()
+            out.append(d)
+        return out
+
     def decisions(self, events=None):
         """{'convXY': bool [B,C,H,W], 'poolX': int64 [B,C,Ho,Wo]} on the CPU, real channels only (the zero-padded network of a
         narrow kernel_size carries pad channels that are identically zero)."""

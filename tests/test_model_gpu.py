@@ -204,6 +204,60 @@ def test_variable_length_minibatch_train_step_vs_float64(monkeypatch):
     assert abs(float(loss2) - float(loss)) < 1e-5 * abs(float(loss)) and float((net.fc1.weight - before).abs().max()) > 0
 
 
+def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buckets(monkeypatch):
+    """The same semantics as the test above — every utterance of a training minibatch at its own length, one dense tail — but as
+    ONE set of launches: the utterances stacked along time, the front-end's forward, data-gradient, weight-gradient, pool and conv11
+    kernels taking the utterance borders from tables (ragged.utterance_vectors_ragged_train; the weight gradient subtracts the
+    cross-border products).  VGG4L at the reference's default width (the stacked path needs channel counts the kernels take without
+    padding).  (1) Loss and every gradient element against the float64 oracle on the same list under the decisions the HIP forward
+    took, flips counted; (2) against the one-dense-pass-per-length path of the same model: same loss, gradients to 4e-5."""
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    from _decisions import DecisionCapture
+    p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
+                           embedding_size=64, num_spkrs=20, scalingFactor=30.0, marginFactor=0.4, annealing=False)
+    torch.manual_seed(5)
+    net = SpeakerClassifier(p, torch.device(DEV)).to(DEV).train()
+    lens = [24, 17, 24, 33, 9]
+    utts = [torch.from_numpy(rnd(2300 + i, n, 80)) for i, n in enumerate(lens)]
+    lab = torch.tensor([3, 0, 7, 19, 1])
+    keep = torch.rand(len(lens), p.heads_number) > 0.3
+    keep[:, 1] = True
+    assert net.ragged_training == "stacked" and net.front_end.ragged_training_ok()
+    monkeypatch.setattr(net.poolingLayer.headsAttention, "draw_head_keep", lambda batch, heads, device: keep.to(device))
+    with DecisionCapture(monkeypatch, net.front_end) as cap:
+        loss, _ = net.forward_loss([u.to(DEV) for u in utts], lab.to(DEV), 0)
+        loss.backward()
+        assert net.last_ragged_buckets is None and len(cap.events) == 12          # ONE pass over the stacked batch
+        decs = cap.decisions_stacked(lens)
+    grads = {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    _, _, own = oracle.train_step_grads(sd, [(utts, lab, keep)], 4, p.marginFactor, p.scalingFactor)
+    flips = sum(sum(oracle.count_flips(own[0][i], decs[i], 4).values()) for i in range(len(lens)))
+    l64, g64, _ = oracle.train_step_grads(sd, [(utts, lab, keep)], 4, p.marginFactor, p.scalingFactor, decisions=[decs])
+    print("stacked variable-length minibatch: loss %.6f (float64 %.6f), %d decisions differ from the float64 forward's"
+          % (float(loss.detach()), l64[0], flips))
+    assert abs(float(loss.detach()) - l64[0]) < 2e-5 * abs(l64[0]) and flips <= 40
+    for n, g in grads.items():
+        ref = g64[n].numpy()
+        atol = 4e-3 if ref.ndim == 1 else 1e-4 * max(1.0, np.abs(ref).max())
+        np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=2e-3, atol=atol, err_msg=n)
+    # (2) the bucketed path of the same model: one dense pass per distinct length
+    from doubleattentionspeakerverification_amd.batching import bucket_by_length
+    buckets = bucket_by_length(lens, max_batch=len(lens))
+    queue = [keep[torch.tensor(b)].to(DEV) for b in buckets]
+    monkeypatch.setattr(net.poolingLayer.headsAttention, "draw_head_keep", lambda batch, heads, device: queue.pop(0))
+    net.ragged_training = "buckets"
+    net.zero_grad(set_to_none=True)
+    loss_b, _ = net.forward_loss([u.to(DEV) for u in utts], lab.to(DEV), 0)
+    loss_b.backward()
+    assert net.last_ragged_buckets == buckets and abs(float(loss_b.detach()) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    for n, q in net.named_parameters():
+        if q.grad is not None:
+            a, b = grads[n], q.grad
+            assert float((a - b).abs().max()) <= 4e-5 * max(1.0, float(b.abs().max())) + (4e-3 if b.dim() == 1 else 0.0), n
+
+
 def test_default_config_embedding_vs_oracle_and_bf16_error():
     """Reference default model (VGG4L/1024, 32 heads, emb 400) on a small batch: fp32 within 1e-3 relative of
     the CPU oracle; the bf16-autocast path's error is reported, not hidden."""
