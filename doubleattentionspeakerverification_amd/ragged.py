@@ -1,4 +1,5 @@
-"""Ragged batches: utterances of DIFFERENT lengths through the front-end in ONE set of launches (inference).
+"""Ragged batches: utterances of DIFFERENT lengths through the front-end in ONE set of launches — inference (embed_ragged) and, through
+the dense autograd functions of conv.py with the border tables threaded through, training (utterance_vectors_ragged_train).
 
 The reference can only run unequal utterances one per forward (train.py:117-133): there are no padding masks anywhere in
 the model, so zero-padding a batch changes the result.  But the convolutions and the pools are position-independent
