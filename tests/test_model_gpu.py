@@ -657,9 +657,9 @@ def test_frontend_training_backward_hip_equals_torch(ks, cmode, monkeypatch):
     cap = {}
 
     def capturing(xx, w, b, packed=None, mode="split", premasked=False, mask_in=False, link_in=None, link_out=None, x_rec=None,
-                  y_rec=None, fuse=True):
+                  y_rec=None, span=None, borders=None, fuse=True):
         y = orig_conv(xx, w, b, packed, mode, premasked and fuse, mask_in and fuse, link_in if fuse else None,
-                      link_out if fuse else None, x_rec, y_rec)
+                      link_out if fuse else None, x_rec, y_rec, span, borders)
         name = [k for k, v in net.named_parameters() if v is w][0].split(".")[0]
         cap[name] = dict(x=xx.detach(), y=y.detach(), premasked=premasked and fuse, mask_in=mask_in and fuse)
         y.register_hook(lambda g, name=name: cap[name].__setitem__("gy", g.detach().clone()))
@@ -671,11 +671,11 @@ def test_frontend_training_backward_hip_equals_torch(ks, cmode, monkeypatch):
     for mode in ("torch", "fused", "unfused"):
         fuse = mode == "fused"
         monkeypatch.setattr(C, "conv3x3_bias_relu", lambda *a, fuse=fuse, **k: capturing(*a, fuse=fuse, **k))
-        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, x_rec=None, y_rec=None, fuse=fuse:
-                            orig_pool(t, relu_input and fuse, link_out if fuse else None, x_rec, y_rec))
+        monkeypatch.setattr(C, "maxpool2x2_ceil_autograd", lambda t, relu_input=False, link_out=None, x_rec=None, y_rec=None, pool_src=None, fuse=fuse:
+                            orig_pool(t, relu_input and fuse, link_out if fuse else None, x_rec, y_rec, pool_src))
         # (conv11 leaves its ReLU mask to conv12's data-gradient kernel in the fused wiring only)
-        monkeypatch.setattr(C, "conv3x3_c1_bias_relu_autograd", lambda t, w, b, y_rec=None, grad_premasked=False, fuse=fuse:
-                            orig_c1(t, w, b, y_rec, grad_premasked and fuse))
+        monkeypatch.setattr(C, "conv3x3_c1_bias_relu_autograd", lambda t, w, b, y_rec=None, grad_premasked=False, span=None, fuse=fuse:
+                            orig_c1(t, w, b, y_rec, grad_premasked and fuse, span))
         net.conv_mode = "torch" if mode == "torch" else cmode
         net.zero_grad()
         cap.clear()
