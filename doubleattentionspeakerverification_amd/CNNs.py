@@ -86,6 +86,9 @@ class _VGG(nn.Module):
         self.fuse_pool = True
         self.pool_tile = 0          # tile shape of the fused launches (0: automatic; measurements force 160 / 192 / 256)
         self.fuse_pool_layers = {(1, "split8"), (2, "split8"), (2, "fp16")}
+        # training (split8): the same one-launch form of convX2 + ReLU + pool (conv.conv3x3_bias_relu_pool) for these blocks — the
+        # launch also writes the pool's arg-max bytes, which is all the backward needs of the full-resolution map
+        self.fuse_pool_training = {1, 2, 3, 4}
         self._packed = {}
 
     def _mode(self):
@@ -272,6 +275,11 @@ class _VGG(nn.Module):
             if not (hip and grad and B == 1 and self.ragged_training_ok(Fdim)):
                 raise RuntimeError("ragged training batches need the split8 mode on the GPU, gradients enabled and exact channel counts")
             spans, pools, borders = tables
+        if hip and grad and any(q.requires_grad for q in self.parameters()):
+            # a pass that an optimizer step may follow: torch's FUSED optimizers update the parameters without moving their version
+            # counters (the packed planes' cache key), so no packed copy made before this pass may be reused after it — neither by
+            # the training passes (they pack on every call, conv.PackedConvWeights) nor by the no-grad chains' own caches
+            _hipconv.invalidate_packed_weights(self)
         if hip and not grad and self.packed_activations and self._mode() == "split8" and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_packed(paddedInputTensor)
         if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
@@ -319,6 +327,16 @@ class _VGG(nn.Module):
             sp, bd = spans[blk - 1], borders[blk - 1]
             if not (hip and blk == 1):
                 h, rh = self._conv_relu(n1, h, grad_premasked=hip2, link_in=l1, x_rec=rh, y_rec=next(recs) if x8 else None, span=sp, borders=bd)
+            c2 = getattr(self, n2)
+            if (grad and x8 and hip2 and pool_hip and sp is None and blk in self.fuse_pool_training and h.dtype == torch.float32
+                    and h.shape[1] == c2.in_channels
+                    and _hipconv.pool_fusable("split8", h.shape[0], h.shape[2], h.shape[3], c2.in_channels, c2.out_channels)):
+                next(recs)          # (the record of the full-resolution map, which does not exist in this form)
+                ry = next(recs)
+                h = _hipconv.conv3x3_bias_relu_pool(h, c2.weight, c2.bias, self._pk(n2, h.device), mask_input_grad=True,
+                                                    link_out=None if (hip and blk == 1) else l1, x_rec=rh, y_rec=ry)
+                rh = ry
+                continue
             if not (fused_first and blk == 1):
                 h, rh = self._conv_relu(n2, h, grad_premasked=hip2 and pool_hip, mask_input_grad=True, link_in=l2,
                                         link_out=None if (hip and blk == 1) else l1,   # conv11's kernel sums its own bias gradient

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dasv_conv3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "dasv_conv3x3_packed_weight_bytes_x8": (c_size_t, [c_int, c_int]),
     "dasv_conv3x3_pack_weights_x8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_pack_weights_x8_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_range_absmax_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_packed_weight_bytes_f16": (c_size_t, [c_int, c_int]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     "dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_ragged_x8_nhwc": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int]),
+    "dasv_conv3x3_colsum_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_masked_x8_nhwc": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_conv3x3_bias_relu_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "dasv_conv3x3_pool_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dasv_conv3x3_bias_relu_pool_x8_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_bias_relu_pool_f16_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_x8_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),

@@ -72,11 +72,14 @@ class PackedConvWeights:
     """bf16 hi/lo planes [Cout][9][Cin] of a Conv2d weight, re-packed when the parameter changes.
 
     The packed planes are reused only for the SAME leaf `nn.Parameter` object (held by weak reference) at the same
-    address and version counter.  Anything else is packed on every call: nn.DataParallel replicas (train.py:68-70
+    address and version counter, and only in passes that cannot be followed by an optimizer step (no gradient is being
+    recorded for the weight).  Anything else is packed on every call: nn.DataParallel replicas (train.py:68-70
     re-broadcasts the weights on every forward; the copies are plain tensors whose version is always 0 and whose
-    allocator addresses repeat), functional weights, transposed temporaries.  Writes through `.data` do not move the
-    version counter: code that updates weights that way (EMA swaps, raw collectives on `.data`) calls `invalidate()` /
-    `invalidate_packed_weights(module)` afterwards."""
+    allocator addresses repeat), functional weights, transposed temporaries — and every TRAINING forward: torch's fused
+    optimizers (`Adam(..., fused=True)`) update the parameters without moving their version counters, so a cached copy
+    would silently go stale after the first step (seven small launches per step, ~1 % of it).  Writes through `.data`
+    do not move the version counter either: code that updates weights that way outside training (EMA swaps, raw
+    collectives on `.data`) calls `invalidate()` / `invalidate_packed_weights(module)` afterwards."""
 
     def __init__(self):
         self.key = None
@@ -88,11 +91,14 @@ class PackedConvWeights:
         self.key = None
         self.owner = None
 
-    def get(self, weight, mode="split", bias=None, pad=None):
+    def get(self, weight, mode="split", bias=None, pad=None, fresh=False):
         """bias: the layer's bias (split8: its maximum enters the bound a packed output is scaled by).
-        pad = (cin_p, cout_p): planes of the zero-padded layer [cout_p][9][cin_p] (and `self.bias` padded to cout_p)."""
+        pad = (cin_p, cout_p): planes of the zero-padded layer [cout_p][9][cin_p] (and `self.bias` padded to cout_p).
+        fresh: a TRAINING pass (the weight's gradient is wanted — an autograd Function's forward knows that from
+        ctx.needs_input_grad; grad mode is off inside it): pack now and keep nothing."""
         kind = _PACK_KIND[mode]
-        cacheable = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
+        leaf = isinstance(weight, torch.nn.Parameter) and weight.is_leaf
+        cacheable = leaf and not fresh and not (torch.is_grad_enabled() and weight.requires_grad)
         cout, cin = weight.shape[0], weight.shape[1]
         if pad is not None and tuple(pad) == (cin, cout):
             pad = None
@@ -112,7 +118,7 @@ class PackedConvWeights:
                 cout, cin = cout_p, cin_p
             n = max(lib.dasv_conv3x3_packed_weight_bytes(cout, cin), lib.dasv_conv3x3_packed_weight_bytes_f16(cout, cin))
             nlo = max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cout, cin))   # the e4m3 plane carries its scale bytes behind it
-            if not cacheable or self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
+            if not leaf or self.hi is None or self.hi.numel() != n or self.hi.device != weight.device:
                 # (weights that are not a leaf Parameter — DataParallel replicas, functional weights — get fresh planes per call:
                 # re-packing into shared buffers would race with a convolution still reading them on another stream)
                 self.hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
@@ -132,6 +138,21 @@ class PackedConvWeights:
             self.key = key if cacheable else None
             self.owner = weakref.ref(weight) if cacheable else None
         return self.hi, self.lo
+
+
+def _pack_dgrad_x8(weight):
+    """split8 planes of a layer's DATA-GRADIENT convolution (weights transposed over (out, in), flipped over (ky, kx)) packed from
+    the layer's own weight [Cout,Cin,3,3] in one launch."""
+    lib = _lib.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    n = max(lib.dasv_conv3x3_packed_weight_bytes(cin, cout), lib.dasv_conv3x3_packed_weight_bytes_f16(cin, cout))
+    hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
+    lo = torch.empty(max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cin, cout)), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.dasv_conv3x3_pack_weights_x8_dgrad(weight.data_ptr(), hi.data_ptr(), lo.data_ptr(), cout, cin,
+                                                    torch.cuda.current_stream(weight.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_pack_weights_x8_dgrad")
+    return hi, lo
 
 
 def invalidate_packed_weights(module):
@@ -177,7 +198,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
             if mask is not None:
-                rows = lib.dasv_conv3x3_colsum_rows(1, H, W) if colsum is not None else 0
+                rows = lib.dasv_conv3x3_colsum_rows(3, 1, H, W, 1) if colsum is not None else 0
                 part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
                 rc = lib.dasv_conv3x3_masked_ragged_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
                                                             y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
@@ -196,7 +217,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if mode == "split8" and mask is not None:
-            rows = lib.dasv_conv3x3_colsum_rows(B, H, W) if colsum is not None else 0
+            rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0) if colsum is not None else 0
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             rc = lib.dasv_conv3x3_masked_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
                                                  None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
@@ -211,7 +232,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                                                     None if y_rec is None else y_rec.data_ptr(),
                                                     None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, relu, stream)
         elif mask is not None:   # y = conv(x) where mask > 0 else 0 (no bias, no ReLU): the fused data-gradient form
-            rows = lib.dasv_conv3x3_colsum_rows(B, H, W) if colsum is not None else 0
+            rows = lib.dasv_conv3x3_colsum_rows(MODES[mode], B, H, W, 0) if colsum is not None else 0
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             rc = lib.dasv_conv3x3_masked_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
                                               y.data_ptr(), None if part is None else part.data_ptr(), B, H, W, cin, cout, stream)
@@ -283,12 +304,13 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
 
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span=None, borders=None):
+    def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span=None, borders=None,
+                fresh=False):
         # x carries cin_x >= Cin channels (a multiple of 64; the surplus is zero) and y gets padded_channels(Cout): the layer runs
         # as its zero-padded form (see `supported`)
         cout, cin = weight.shape[0], weight.shape[1]
         cin_x, cout_p = x.shape[1], padded_channels(cout)
-        hi, lo = packed.get(weight, mode, bias, (cin_x, cout_p))
+        hi, lo = packed.get(weight, mode, bias, (cin_x, cout_p), fresh=fresh)
         bias_k = packed.bias if (cin_x, cout_p) != (cin, cout) and bias is not None else bias
         if mode == "split8" and x_rec is None:
             x_rec = range_of(x)
@@ -309,71 +331,142 @@ class _ConvReLUFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         # ReLU backward in one pass (g = gy where y > 0 else 0) — unless the consumer of y already applied it
         g = gy if ctx.grad_premasked else torch.ops.aten.threshold_backward(gy, y, 0.0)
-        cout, cin = weight.shape[0], weight.shape[1]
-        cin_x, cout_p = x.shape[1], y.shape[1]        # the padded layer that ran forward
-        padded = (cin_x, cout_p) != (cin, cout)
-        gx = None
-        bmode = BACKWARD_MODE[ctx.mode]
-        dmode = DGRAD_MODE[ctx.mode] if x.shape[3] <= 80 else bmode       # (the split8 form exists in the window kernel only)
-        # split8 data gradient: the incoming gradient's range record rides on the tensor when a kernel of this library produced it
-        # (the layer above's data gradient, the pool's backward); otherwise one pass over it measures it
-        g_rec = _rec_of(gy) if dmode == "split8" else None
-        gx_rec = new_ranges(x.device)[0] if dmode == "split8" else None
-        want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if want_x and g.dtype == torch.float32:
-            # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution of g with the weights
-            # transposed over (Cout, Cin) and flipped over (ky, kx): reuse the forward implicit-GEMM kernel
-            # (the kernel writes 128-channel tiles: an input with a 64-multiple of channels gets its gradient through a padded
-            # transposed layer and a slice — narrow kernel sizes only)
-            n_out = (cin_x + 127) // 128 * 128
+        return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1]) + (None,) * 11
+
+
+def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
+    """(gx, gw, gb) of a conv3x3 + bias layer from g = the gradient at its pre-activation [B, cout_p, H, W] (channels_last fp32; g_rec_in
+    its range record or None) — shared by the layer's own autograd node and by the conv + ReLU + max-pool node."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    cin_x = x.shape[1]        # (with cout_p: the padded layer that ran forward)
+    padded = (cin_x, cout_p) != (cin, cout)
+    gx = None
+    bmode = BACKWARD_MODE[ctx.mode]
+    dmode = DGRAD_MODE[ctx.mode] if x.shape[3] <= 80 else bmode       # (the split8 form exists in the window kernel only)
+    # split8 data gradient: the incoming gradient's range record rides on the tensor when a kernel of this library produced it
+    # (the layer above's data gradient, the pool's backward); otherwise one pass over it measures it
+    g_rec = g_rec_in if dmode == "split8" else None
+    gx_rec = new_ranges(x.device)[0] if dmode == "split8" else None
+    want_x, want_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    want_b = ctx.has_bias and ctx.needs_input_grad[2]
+    if want_x and g.dtype == torch.float32:
+        # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution of g with the weights
+        # transposed over (Cout, Cin) and flipped over (ky, kx): reuse the forward implicit-GEMM kernel
+        # (the kernel writes 128-channel tiles: an input with a 64-multiple of channels gets its gradient through a padded
+        # transposed layer and a slice — narrow kernel sizes only)
+        n_out = (cin_x + 127) // 128 * 128
+        if dmode == "split8" and not padded and n_out == cin_x and weight.dtype == torch.float32 and weight.is_contiguous():
+            hi, lo = _pack_dgrad_x8(weight.detach())      # straight from the layer's weight: no transposed copy
+        else:
             wt = weight.detach()
             if padded or n_out != cin_x:
                 wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, n_out - cin, 0, cout_p - cout))
             wt = wt.transpose(0, 1).flip(2, 3).contiguous()
             pk = PackedConvWeights()
             hi, lo = pk.get(wt, dmode)
-            if n_out == cin_x:
-                # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
-                # backward is applied in this kernel's epilogue
-                gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
-                             colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span)
-                if gx_rec is not None:
-                    _attach_rec(gx, gx_rec)
-            else:
-                gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec, span=ctx.span)[:, :cin_x].contiguous(memory_format=torch.channels_last)
-                if ctx.mask_input_grad:
-                    gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
-            want_x = False
-        gw = gb = None
-        if want_w and USE_HIP_WGRAD and supported_wgrad(cin_x, cout_p, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
-            wmode = WGRAD_MODE[ctx.mode]
-            # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
-            gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
-                               g_rec=_rec_of(gy) if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None)
-            if padded:
-                gw = gw[:cout, :cin].contiguous()
-            want_w = False
-            if want_b:
-                # the kernel that produced this (pre-masked) gradient may have left its per-channel sums behind
-                gb = ctx.link_in.pop("gb", None) if (ctx.grad_premasked and ctx.link_in is not None) else None
-                if gb is None:
-                    gb = g.sum(dim=(0, 2, 3))
-                gb = gb[:cout] if padded else gb
-                want_b = False
-        if (want_x or want_w or want_b) and ctx.span is not None:
-            raise RuntimeError("ragged training batch: a gradient fell outside the hand-written kernels' limits (operands beyond 4 GB?)")
-        if want_x or want_w or want_b:
-            # (maps wider than 80 columns / operands beyond 4 GB only: the weight-gradient kernel's limits)
-            wfull = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin_x - cin, 0, cout_p - cout)) if padded else weight
-            gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
-                g, x, wfull, [cout_p] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                [want_x, want_w, want_b])
-            if want_x:
-                gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
-            gw = (gw2[:cout, :cin].contiguous() if padded else gw2) if want_w else gw
-            gb = (gb2[:cout] if padded else gb2) if want_b else gb
-        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
+        if n_out == cin_x:
+            # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
+            # backward is applied in this kernel's epilogue
+            gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
+                         colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span)
+            if gx_rec is not None:
+                _attach_rec(gx, gx_rec)
+        else:
+            gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec, span=ctx.span)[:, :cin_x].contiguous(memory_format=torch.channels_last)
+            if ctx.mask_input_grad:
+                gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
+        want_x = False
+    gw = gb = None
+    if want_w and USE_HIP_WGRAD and supported_wgrad(cin_x, cout_p, x.shape[3], x.shape[0] * x.shape[2] * x.shape[3]) and g.dtype == torch.float32:
+        wmode = WGRAD_MODE[ctx.mode]
+        # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
+        gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
+                           g_rec=g_rec_in if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None)
+        if padded:
+            gw = gw[:cout, :cin].contiguous()
+        want_w = False
+        if want_b:
+            # the kernel that produced this (pre-masked) gradient may have left its per-channel sums behind
+            gb = ctx.link_in.pop("gb", None) if (ctx.grad_premasked and ctx.link_in is not None) else None
+            if gb is None:
+                gb = g.sum(dim=(0, 2, 3))
+            gb = gb[:cout] if padded else gb
+            want_b = False
+    if (want_x or want_w or want_b) and ctx.span is not None:
+        raise RuntimeError("ragged training batch: a gradient fell outside the hand-written kernels' limits (operands beyond 4 GB?)")
+    if want_x or want_w or want_b:
+        # (maps wider than 80 columns / operands beyond 4 GB only: the weight-gradient kernel's limits)
+        wfull = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin_x - cin, 0, cout_p - cout)) if padded else weight
+        gx2, gw2, gb2 = torch.ops.aten.convolution_backward(
+            g, x, wfull, [cout_p] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            [want_x, want_w, want_b])
+        if want_x:
+            gx = torch.ops.aten.threshold_backward(gx2, x, 0.0) if ctx.mask_input_grad else gx2
+        gw = (gw2[:cout, :cin].contiguous() if padded else gw2) if want_w else gw
+        gb = (gb2[:cout] if padded else gb2) if want_b else gb
+    return gx, gw, gb
+
+
+class _ConvReLUPoolFn(torch.autograd.Function):
+    """`F.max_pool2d(F.relu(convX2(x)), 2, stride=2, ceil_mode=True)` (CNNs.py:73-74 ... 85-86) as ONE forward launch in training
+    (dasv_conv3x3_bias_relu_pool_idx_x8_nhwc): the pooled map plus one byte per pooled element {arg-max | 4 if the maximum is > 0}.
+    The backward scatters the pooled gradient through those bytes (which apply the ReLU's mask too and leave the bias gradient
+    behind), then runs the layer's weight- and data-gradient launches; the full-resolution activation map never exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, mask_input_grad, link_out, x_rec, y_rec, fresh=True):
+        lib = _lib.load()
+        cout, cin = weight.shape[0], weight.shape[1]
+        B, cin_x, H, W = x.shape
+        hi, lo = packed.get(weight, "split8", bias, fresh=fresh)
+        if x_rec is None:
+            x_rec = range_of(x)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                             None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                             None if y_rec is None else y_rec.data_ptr(), idx.data_ptr(), B, H, W, cin_x, cout,
+                                                             torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
+        ctx.save_for_backward(x, weight, idx)
+        ctx.x_rec, ctx.has_bias, ctx.mode = x_rec, bias is not None, "split8"
+        ctx.grad_premasked, ctx.mask_input_grad = True, mask_input_grad
+        ctx.link_in, ctx.link_out = {}, link_out
+        ctx.span = ctx.borders = None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, idx = ctx.saved_tensors
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        C = weight.shape[0]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(gy.device):
+            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if ctx.has_bias else 0
+            part = torch.empty((rows, C), dtype=torch.float32, device=gy.device) if rows > 0 else None
+            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), g.data_ptr(), None if part is None else part.data_ptr(),
+                                                       1, B, H, W, C, torch.cuda.current_stream(gy.device).cuda_stream)
+        _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
+        if part is not None:
+            ctx.link_in["gb"] = part.sum(dim=0)
+        # (the scattered gradient's range record is its source's: max |g| <= max |gy|)
+        return _conv_backward(ctx, x, weight, g, _rec_of(gy), C) + (None,) * 6
+
+
+def conv3x3_bias_relu_pool(x, weight, bias, packed=None, mask_input_grad=False, link_out=None, x_rec=None, y_rec=None):
+    """Differentiable `max_pool2d(relu(conv2d(x, weight, bias, padding 1)), 2, stride=2, ceil_mode=True)` in the split8 mode for shapes
+    `pool_fusable("split8", ...)` accepts (x [B,Cin,H,W] channels_last fp32): one forward launch, no full-resolution map.
+    mask_input_grad / link_out / x_rec / y_rec as in conv3x3_bias_relu."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("conv3x3_bias_relu_pool runs on fp32 GPU tensors only (libdasv_hip.so); no CPU fallback")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    fresh = torch.is_grad_enabled() and weight.requires_grad
+    return _ConvReLUPoolFn.apply(x, weight, bias, packed or PackedConvWeights(), mask_input_grad, link_out, x_rec, y_rec, fresh)
 
 
 def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
@@ -410,7 +503,10 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         mode = "split"   # the fp16 + e4m3 form exists in the window kernel (maps up to 80 columns) only
     packed = packed or PackedConvWeights()
     b = None if bias is None else bias.detach().float().contiguous() if not bias.requires_grad else bias
-    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders)
+    # (a training pass — the weight's gradient is being recorded — packs the planes afresh: PackedConvWeights; decided here because
+    # grad mode is off inside an autograd Function's forward and ctx.needs_input_grad ignores torch.no_grad())
+    fresh = torch.is_grad_enabled() and weight.requires_grad
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders, fresh)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):

@@ -124,16 +124,21 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                                                       uint16_t* __restrict__ wh, uint8_t* __restrict__ w8, int Cout, int Cin) {
+                                                                       uint16_t* __restrict__ wh, uint8_t* __restrict__ w8, int Cout, int Cin,
+                                                                       int transposed) {
     __shared__ float red[4];
     const int o = blockIdx.x, tid = threadIdx.x, n = 9 * Cin;
-    const float* wo = w + (size_t)o * n;
+    // transposed: w is the weight [Cin][Cout][3][3] of the layer whose DATA GRADIENT these planes compute — the same convolution with
+    // the weights transposed over (out, in) and flipped over (ky, kx): plane element (o, tap, c) = w[c][o][8 - tap]
+    auto src = [&](int c, int tap) -> float {
+        return transposed ? w[((size_t)c * Cout + o) * 9 + (8 - tap)] : w[((size_t)o * Cin + c) * 9 + tap];
+    };
     uint8_t* aux = w8 + (size_t)Cout * n * 2;
     float* winv = reinterpret_cast<float*>(aux + (size_t)Cout * 4);
     uint32_t* tail = reinterpret_cast<uint32_t*>(aux + (size_t)Cout * 8);   // zeroed by the host wrapper before this launch
     float mw = 0.f, l1 = 0.f;
     for (int i = tid; i < n; i += 256) {
-        const float v = wo[i];
+        const float v = src(i / 9, i % 9);
         mw = fmaxf(mw, fabsf(v));
         l1 += fabsf(v);
     }
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const floa
     const float sw = x8_pow2(Ew);
     float mr = 0.f;
     for (int i = tid; i < n; i += 256) {
-        const float c = wo[i] * sw;
+        const float c = src(i / 9, i % 9) * sw;
         mr = fmaxf(mr, fabsf(c - (float)(_Float16)c));
     }
     mr = block_max256(mr, red);
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const floa
     const int nslab = Cin / 64;
     for (int i = tid; i < n; i += 256) {
         const int c = i % Cin, tap = i / Cin;          // destination order (tap, cin)
-        const float v = wo[(size_t)c * 9 + tap] * sw;
+        const float v = src(c, tap) * sw;
         const _Float16 h = (_Float16)v;
         wh[(size_t)o * n + i] = __builtin_bit_cast(uint16_t, h);
         const float r = (v - (float)h) * sl;
@@ -267,6 +272,9 @@ struct ConvParams {
     // covers `pool_units` whole ROW PAIRS (units; the last unit of an image with an odd H is a single row) instead of TBM raster
     // pixels, so that every 2x2 window lies inside one tile: pool_units * 2 * W <= TBM, pool_U = ceil(H/2) units per image.
     int pool, pool_units, pool_U;
+    uint8_t* pool_idx;     // (training, fp32 y) [B, ceil(H/2), ceil(W/2), Cout] bytes {arg-max position 0-3 | 4 if the maximum is > 0}: what
+                           // the pool's backward needs (frontend_misc.hip, maxpool2x2_bwd_nhwc_kernel) — the full-resolution map is
+                           // then needed by nobody
 };
 
 // LDS: four planes of 128 rows x 128 bytes (64 bf16): A_hi | A_lo | B_hi | B_lo.  16-byte slot s of row r lives at
@@ -1310,7 +1318,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     // channels] rows of 528 bytes (the 16-byte pad makes the b128 writes of 8 pixels hit 32 distinct banks) — and is written out
     // as whole 512-byte pixel rows, two per wave-instruction.
     if constexpr (PIPELINED) {
-        if (p.mask == nullptr && p.colsum == nullptr) {
+        {
             constexpr int OP = 528;
             DASV_STAMP(60);
             __syncthreads();                     // every wave is done with the window and the tiles
@@ -1328,7 +1336,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 for (int i = 0; i < IB; ++i) {
                     f32x4 v = (SCALED ? acc[i][j] * sc : acc[i][j]) + bv;
                     if (p.relu) v = relu4(v);
-                    if (GEOM == 1 ? gh0 + wm * IB + i < H : m0 + wm * (16 * IB) + i * 16 + (lane & 15) < mend) note4(v);
+                    // (a masked output is noted where the mask is applied: the write-out pass below)
+                    if (p.mask == nullptr && (GEOM == 1 ? gh0 + wm * IB + i < H : m0 + wm * (16 * IB) + i * 16 + (lane & 15) < mend)) note4(v);
                     char* row = smem + (wm * (16 * IB) + i * 16 + (lane & 15)) * OP;
                     if (p.pool) {
                         // fused max-pool: the image holds the fp32 values; the output form is applied to the pooled values below
@@ -1396,9 +1405,27 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     }
                     const char* src = smem + lp * OP + col * 16;
                     f32x4 v = *reinterpret_cast<const f32x4*>(src);
-                    if (c1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + OP));
-                    if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + rowp * OP));
-                    if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (rowp + 1) * OP));
+                    if (p.pool_idx != nullptr) {
+                        // row-major scan, strict '>': the first maximum wins, as ATen's kernel does (and a NaN takes over) — the
+                        // bytes dasv_maxpool2x2_ceil_idx_nhwc writes
+                        int arg[4] = {0, 0, 0, 0};
+                        auto mxa = [&](f32x4 t, int pos) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (t[c] > v[c] || t[c] != t[c]) { v[c] = t[c]; arg[c] = pos; }
+                        };
+                        if (c1) mxa(*reinterpret_cast<const f32x4*>(src + OP), 1);
+                        if (r1) mxa(*reinterpret_cast<const f32x4*>(src + rowp * OP), 2);
+                        if (c1 && r1) mxa(*reinterpret_cast<const f32x4*>(src + (rowp + 1) * OP), 3);
+                        uint32_t code = 0u;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) code |= (uint32_t)(arg[c] | (v[c] > 0.f ? 4 : 0)) << (8 * c);
+                        *reinterpret_cast<uint32_t*>(p.pool_idx + (size_t)op * p.Cout + n0 + col * 4) = code;
+                    } else {
+                        if (c1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + OP));
+                        if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + rowp * OP));
+                        if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (rowp + 1) * OP));
+                    }
                     if (PREC == PREC_F16 && p.y_packed == 2) {
                         const f32x4 qv = v * sy;
                         const f16x2_t a = __builtin_convertvector(f32x2_t{qv[0], qv[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{qv[2], qv[3]}, f16x2_t);
@@ -1429,13 +1456,63 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 return;
             }
             const int col = tid & 31;            // 16-byte chunk of a pixel's 512-byte row; 16 pixels per pass of the workgroup
+            if (p.mask == nullptr && p.colsum == nullptr) {
 #pragma unroll
-            for (int k = 0; k < TBM / 16; ++k) {
-                const int pix = (tid >> 5) + 16 * k;
-                int m = m0 + pix;
-                if constexpr (GEOM == 1) m = gh0 + (pix >> 4) < H ? (gb * H + gh0 + (pix >> 4)) * W + gw0 + (pix & 15) : p.M;
-                if (m < p.M)
-                    *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
+                for (int k = 0; k < TBM / 16; ++k) {
+                    const int pix = (tid >> 5) + 16 * k;
+                    int m = m0 + pix;
+                    if constexpr (GEOM == 1) m = gh0 + (pix >> 4) < H ? (gb * H + gh0 + (pix >> 4)) * W + gw0 + (pix & 15) : p.M;
+                    if (m < p.M)
+                        *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n0 + col * 4) = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
+                }
+                DASV_STAMP(63);
+                return;
+            }
+            // data-gradient launches (a ReLU's backward fused: outputs zeroed where mask <= 0; per-channel sums of the stored rows =
+            // the bias gradient of the layer below): the mask is read, and the output written, in the same whole 512-byte pixel rows;
+            // the mask rows of the first passes are requested before the image is read
+            static_assert(NT == 512, "16 pixel rows per pass");
+            f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+            constexpr int KB = 4;               // passes whose mask rows are in flight together
+#pragma unroll
+            for (int k0 = 0; k0 < TBM / 16; k0 += KB) {
+                f32x4 mk[KB];
+                int mm[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const int pix = (tid >> 5) + 16 * (k0 + k);
+                    int m = m0 + pix;
+                    if constexpr (GEOM == 1) m = gh0 + (pix >> 4) < H ? (gb * H + gh0 + (pix >> 4)) * W + gw0 + (pix & 15) : p.M;
+                    if (k0 + k >= TBM / 16) m = p.M;
+                    mm[k] = m;
+                    mk[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (p.mask != nullptr && m < p.M) mk[k] = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n0 + col * 4);
+                }
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    if (mm[k] < p.M) {
+                        const int pix = (tid >> 5) + 16 * (k0 + k);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(smem + pix * OP + col * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = mk[k][r] > 0.f ? v[r] : 0.f;
+                        if (p.mask != nullptr) note4(v);
+                        *reinterpret_cast<f32x4*>(p.y + (size_t)mm[k] * p.Cout + n0 + col * 4) = v;
+                        csum += v;
+                    }
+                }
+            }
+            if (p.mask != nullptr && p.y_rec != nullptr) range_note(p.y_rec, amax_u, rec_seen);
+            if (p.colsum != nullptr) {           // fixed order: a thread's pixel rows (above), then the 16 pixel-row groups
+                float* red = reinterpret_cast<float*>(smem);
+                __syncthreads();                 // every thread is done with the image
+                *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + col * 4) = csum;
+                __syncthreads();
+                if (tid < 128) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
+                    p.colsum[(size_t)mt * p.Cout + n0 + tid] = t;
+                }
             }
             DASV_STAMP(63);
             return;
@@ -1574,7 +1651,18 @@ int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16,
     hipError_t e = hipMemsetAsync(static_cast<char*>(w_e4m3) + (size_t)Cout * 9 * Cin * 2 + (size_t)Cout * 8, 0, 16, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w, bias,
-                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin);
+                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin, 0);
+    return (int)hipGetLastError();
+}
+
+int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
+    if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
+    if (Cout <= 0 || Cin <= 0 || Cout % 64 != 0) return DASV_E_SHAPE;
+    // planes of the convolution with Cin outputs and Cout inputs
+    hipError_t e = hipMemsetAsync(static_cast<char*>(w_e4m3) + (size_t)Cin * 9 * Cout * 2 + (size_t)Cin * 8, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, w, nullptr,
+                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 1);
     return (int)hipGetLastError();
 }
 
@@ -1602,7 +1690,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
                           const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, const uint32_t* x_rec = nullptr,
-                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0) {
+                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1624,7 +1712,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
     if ((x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
     p.row_span = row_span;
-    p.pool = 0; p.pool_units = 0; p.pool_U = 0;
+    p.pool = 0; p.pool_units = 0; p.pool_U = 0; p.pool_idx = pool_idx;
+    if (pool_idx != nullptr && (!pool || y_packed)) return DASV_E_SHAPE;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     // fused max-pool: dense batches, plain epilogue (no mask / column sums / split-K), relu'd outputs
     if (pool && (row_span != nullptr || mask != nullptr || colsum != nullptr || mel != nullptr || W > 80 || !relu)) return DASV_E_SHAPE;
@@ -1638,10 +1727,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
         const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
         // 192-pixel tiles where the 256-pixel window leaves no room for the second tile buffer (80-column maps) but the 192-pixel
-        // one does: the launch then runs the pipelined double-buffered loops.  Not for the column-sum form (its partial rows are
-        // counted in 256-pixel tiles, dasv_conv3x3_colsum_rows) and not for split-K launches.
-        const bool t192 = two && lds256 + 32768 + 128 > 160 * 1024 && lds192 + 32768 + 128 <= 160 * 1024 && S == 1 &&
-                          colsum == nullptr && mel == nullptr;
+        // one does: the launch then runs the pipelined double-buffered loops.  Not for split-K launches.
+        // (dasv_conv3x3_colsum_rows repeats this choice of tiles: keep the two in step)
+        const bool t192 = two && lds256 + 32768 + 128 > 160 * 1024 && lds192 + 32768 + 128 <= 160 * 1024 && S == 1 && mel == nullptr;
         const int tbm = t192 ? 192 : dasv::WBM;
         p.mtiles = (p.M + tbm - 1) / tbm;
         const size_t lds1 = t192 ? lds192 : lds256;
@@ -1649,13 +1737,13 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         // (round 1 measured the double buffer alone as a loss for bf16 operands — with the un-pipelined loop)
         const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
         // patch tiles (GEOM = 1): maps whose width is a multiple of 16 and whose raster window would be larger than the 18 x 18
-        // patch window (80 / 64 / 48 columns; the 80-column first block in this model) — pipelined fp16 / split8 launches without
-        // masks, column sums, ragged borders or split-K
+        // patch window (80 / 64 / 48 columns; the 80-column first block in this model) — pipelined split8 launches (forward and
+        // masked data gradient) without ragged borders or split-K
         // (measured, tools/_diag/pool_fuse_ab.py, profiles/r04_pool_fusion_ab.txt: split8 on [64,300,80] -1.7 % of the front-end's time
         // for the plain layer and -5.6 % with the fused pool; with fp16 operands, whose raster form already has 256-pixel tiles there,
         // the patch form is 4.5 % SLOWER — more address arithmetic per staged chunk — so it is a split8 geometry)
-        const bool patch = mode == 3 && W % 16 == 0 && W >= 48 && mask == nullptr && colsum == nullptr && mel == nullptr &&
-                           row_span == nullptr && S == 1 && pool_tile == 0 && dasv::g_patch_tiles;
+        const bool patch = mode == 3 && W % 16 == 0 && W >= 48 && mel == nullptr && row_span == nullptr && S == 1 && pool_tile == 0 &&
+                           dasv::g_patch_tiles;
         if (patch) {
             p.mtiles = B * ((H + 15) / 16) * (W / 16);
             p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
@@ -1808,6 +1896,15 @@ int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint3
                           y_packed ? 1 : 0, x_range, y_range, 1, tile_pixels);
 }
 
+int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const float* bias,
+                                            float* y, uint32_t* y_range, uint8_t* idx, int B, int H, int W, int Cin, int Cout,
+                                            dasv_stream_t stream) {
+    if (idx == nullptr) return DASV_E_NULL;
+    if (!dasv_conv3x3_pool_supported(3, B, H, W, Cin, Cout)) return DASV_E_SHAPE;
+    return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr, y, nullptr, 0, B, H, W, Cin, Cout, 1,
+                          stream, nullptr, 0, 0, x_range, y_range, 1, 0, idx);
+}
+
 int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
                                          void* y, int y_f16, uint32_t* y_range, int B, int H, int W, int Cin, int Cout,
                                          int tile_pixels, dasv_stream_t stream) {
@@ -1887,9 +1984,16 @@ int dasv_conv3x3_masked_ragged_x8_nhwc(const float* x, const uint32_t* x_range, 
                           Cin, Cout, 0, stream, row_span, 0, 0, x_range, y_range);
 }
 
-int dasv_conv3x3_colsum_rows(int B, int H, int W) {
-    if (B <= 0 || H <= 0 || W <= 0 || W > 80) return 0;
-    return (int)(((long long)B * H * W + dasv::WBM - 1) / dasv::WBM);
+int dasv_conv3x3_colsum_rows(int mode, int B, int H, int W, int ragged) {
+    if (B <= 0 || H <= 0 || W <= 0 || W > 80 || mode < 0 || mode > 3 || (ragged && B != 1)) return 0;
+    // the pixel tiles of a column-sum launch (never split-K): conv3x3_launch's choice, repeated
+    const bool two = mode == 0 || mode == 3;
+    const size_t lds256 = (size_t)(dasv::WBM + 2 * W + 2) * 128 * (two ? 2 : 1) + 32768;
+    const size_t lds192 = (size_t)(192 + 2 * W + 2) * 128 * 2 + 32768;
+    const bool t192 = two && lds256 + 32768 + 128 > 160 * 1024 && lds192 + 32768 + 128 <= 160 * 1024;
+    if (mode == 3 && W % 16 == 0 && W >= 48 && !ragged && dasv::g_patch_tiles) return B * ((H + 15) / 16) * (W / 16);
+    const int tbm = t192 ? 192 : dasv::WBM;
+    return (int)(((long long)B * H * W + tbm - 1) / tbm);
 }
 
 int dasv_conv3x3_c1_conv3x3_bias_relu_nhwc(int mode, const float* mel, const float* w1, const float* b1, const void* w_hi,

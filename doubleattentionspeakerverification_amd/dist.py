@@ -299,6 +299,10 @@ class DataParallelTrainer:
             self.reducer.finish()
             hidden = self.reducer.hide_unused()
             self.opt.step()
+            # (the fused optimizers do not move the parameters' version counters: packed copies of the convolution weights made by
+            # a no-grad forward before this step must not survive it)
+            from .conv import invalidate_packed_weights
+            invalidate_packed_weights(self.net)
             self.reducer.restore(hidden)
             self.reducer.zero()  # grads are views of the flat buffer: one memset instead of zero_grad()
         return loss.detach(), costh.detach()

@@ -151,7 +151,8 @@ int dasv_conv3x3_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, 
  * output that scales a half-precision output tensor; w_f16 holds dasv_conv3x3_packed_weight_bytes_f16(Cout, Cin) bytes) */
 size_t dasv_conv3x3_packed_weight_bytes_f16(int Cout, int Cin);
 int dasv_conv3x3_pack_weights_f16(const float* w, const float* bias, void* w_f16, int Cout, int Cin, dasv_stream_t stream);
-/*       mode 3 ("split8"): fp32-grade on fewer matrix-pipe cycles, FORWARD / activations only, maps up to 80 columns: the
+/*       mode 3 ("split8"): fp32-grade on fewer matrix-pipe cycles, maps up to 80 columns (forward here, data gradient through
+ *               dasv_conv3x3_masked_x8_nhwc, weight gradient through dasv_conv3x3_wgrad_x8_nhwc): the
  *               operand c = v * 2^E is split c = hi + r with hi = fp16(c); hi*hi on the fp16 MFMA, both cross terms hi*r' + r*hi'
  *               on one block-scaled e4m3 MFMA per 64 input channels (residuals are 2^-11 of the value, 4 significant bits
  *               suffice).  ~1e-5 of the output scale against a float64 convolution (mode 0: 5e-6, mode 2: 3e-4) at ANY
@@ -161,10 +162,14 @@ int dasv_conv3x3_pack_weights_f16(const float* w, const float* bias, void* w_f16
  *               mode argument of the generic entry points returns DASV_E_NULL for it: they carry no range records).
  *               w_hi = the fp16 plane and w_lo = the e4m3 planes + scales of dasv_conv3x3_pack_weights_x8 (bias: the layer's
  *               bias or NULL — its maximum bounds the layer's output); w_lo holds dasv_conv3x3_packed_weight_bytes_x8(Cout, Cin)
- *               bytes.  Gradients go through mode 0. */
+ *               bytes.
+ *               dasv_conv3x3_pack_weights_x8_dgrad packs, straight from the FORWARD layer's weight w [Cout][Cin][3][3], the planes
+ *               of that layer's data-gradient convolution (Cin outputs, Cout inputs: the weights transposed over (out, in) and
+ *               flipped over (ky, kx) — no transposed copy is made): w_f16 / w_e4m3 sized for (Cin, Cout). */
 size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin);
 int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16, void* w_e4m3, int Cout, int Cin,
                                  dasv_stream_t stream);
+int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
 
 /* RANGE RECORDS.  A range record is uint32_t[2] in device memory beside an activation tensor: [0] = the bit pattern of
  * max |v| over the tensor (kept by the kernel that writes the tensor with an atomic maximum; the caller zeroes the record
@@ -186,11 +191,13 @@ int dasv_conv3x3_bias_relu_nhwc_ws(int mode, const float* x, const void* w_hi, c
 /* y = conv3x3(x) where mask > 0, else 0 (mask [B,H,W,Cout]).  The data gradient of `F.relu(convX2(F.relu(convX1(h))))`
  * w.r.t. convX1's pre-activation in one launch: x = gradient at convX2's output (already masked), weights = convX2's
  * transposed and flipped, mask = convX2's input (= convX1's ReLU output).  Saves autograd's threshold_backward pass.
- * colsum_partial (optional, maps up to 80 columns): [dasv_conv3x3_colsum_rows(B,H,W)][Cout] per-channel sums of the rows of y
- * each workgroup wrote; their sum over the first axis is convX1's bias gradient (autograd's separate `sum` pass). */
+ * colsum_partial (optional, maps up to 80 columns): [dasv_conv3x3_colsum_rows(mode,B,H,W,ragged)][Cout] per-channel sums of the
+ * rows of y each workgroup wrote (one row per pixel tile of the launch — the tile shape follows mode and map width, hence the
+ * query; ragged = 1 for the *_ragged_* entry points, where B = 1 and H = the stacked rows); their sum over the first axis is
+ * convX1's bias gradient (autograd's separate `sum` pass). */
 int dasv_conv3x3_masked_nhwc(int mode, const float* x, const void* w_hi, const void* w_lo, const float* mask, float* y,
                              float* colsum_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
-int dasv_conv3x3_colsum_rows(int B, int H, int W);
+int dasv_conv3x3_colsum_rows(int mode, int B, int H, int W, int ragged);
 /* The same in the split8 mode (mode 3 above), which the range records make usable for GRADIENTS too: x (the gradient at the upper
  * layer's output, any magnitude — 1e-8 is common) is scaled into the operand planes' range by its record, the transposed weights
  * per channel.  x_range required, y_range optional (receives max |y|: the next layer down scales ITS gradient by it). */
@@ -347,6 +354,13 @@ int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint3
 int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
                                          void* y, int y_f16, uint32_t* y_range, int B, int H, int W, int Cin, int Cout,
                                          int tile_pixels, dasv_stream_t stream);
+/* The TRAINING form (train.py:215-220 through the same lines of CNNs.py): fp32 x, fp32 pooled y, and idx [B, ceil(H/2), ceil(W/2), Cout]
+ * bytes {arg-max position 0-3 (row-major in the window, the first maximum wins — ATen's tie-breaking) | 4 if the maximum is > 0}, the
+ * bytes dasv_maxpool2x2_ceil_idx_nhwc writes: dasv_maxpool2x2_ceil_bwd_idx_nhwc(relu_mask = 1) turns the pooled gradient into the
+ * gradient at convX2's pre-activation from them alone, so the full-resolution activation map is neither written nor kept. */
+int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const float* bias,
+                                            float* y, uint32_t* y_range, uint8_t* idx, int B, int H, int W, int Cin, int Cout,
+                                            dasv_stream_t stream);
 int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,

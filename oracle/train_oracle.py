@@ -117,7 +117,13 @@ def count_flips(own, other, n_blocks):
     `own` must come from vgg_forward_decided(record=...) (it carries the pool inputs)."""
     flips = {}
     for name in vgg_layer_names(n_blocks):
-        if name.startswith("conv"):
+        if name.startswith("conv") and name.endswith("2"):
+            # convX2 feeds the pool: only the sign of the element a window hands on has any effect (forward and backward), and a
+            # one-launch conv + ReLU + pool only knows that one — compared where `other`'s pool hands on
+            idx = other["pool" + name[4]].flatten(2)
+            sel = torch.zeros(own[name].flatten(2).shape, dtype=torch.bool).scatter_(2, idx, True).view(own[name].shape)
+            flips[name] = int(((own[name] != other[name]) & sel).sum())
+        elif name.startswith("conv"):
             flips[name] = int((own[name] != other[name]).sum())
         else:
             h = own["in:" + name].flatten(2)

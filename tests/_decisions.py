@@ -21,7 +21,14 @@ class DecisionCapture:
 
     def __enter__(self):
         C = self.C
-        oc, op, o1 = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd, C.conv3x3_c1_bias_relu_autograd
+        oc, op, o1, ocp = C.conv3x3_bias_relu, C.maxpool2x2_ceil_autograd, C.conv3x3_c1_bias_relu_autograd, C.conv3x3_bias_relu_pool
+
+        def convpool(x, *a, **k):
+            # conv + ReLU + pool in one launch: the only record of its decisions are the bytes {arg-max | 4 if maximum > 0} the
+            # launch leaves for its own backward (saved on the autograd node)
+            y = ocp(x, *a, **k)
+            self.events.append(("convpool", (y.grad_fn.saved_tensors[2].detach(), x.shape[2], x.shape[3])))
+            return y
 
         def conv(*a, **k):
             y = oc(*a, **k)
@@ -40,6 +47,7 @@ class DecisionCapture:
         self.mp.setattr(C, "conv3x3_bias_relu", conv)
         self.mp.setattr(C, "conv3x3_c1_bias_relu_autograd", c1)
         self.mp.setattr(C, "maxpool2x2_ceil_autograd", pool)
+        self.mp.setattr(C, "conv3x3_bias_relu_pool", convpool)
         return self
 
     def __exit__(self, *exc):
@@ -48,9 +56,14 @@ class DecisionCapture:
 
     def passes(self):
         """Decisions of every forward pass captured since reset(), in order (a variable-length minibatch is several dense passes)."""
-        n = 3 * self.fe.n_blocks
-        assert len(self.events) % n == 0, len(self.events)
-        return [self.decisions(self.events[k:k + n]) for k in range(0, len(self.events), n)]
+        out, k = [], 0
+        while k < len(self.events):
+            n = 0
+            for _ in range(self.fe.n_blocks):       # a block is conv, conv, pool — or conv, conv+pool
+                n += 2 if self.events[k + n + 1][0] == "convpool" else 3
+            out.append(self.decisions(self.events[k:k + n]))
+            k += n
+        return out
 
     def decisions_stacked(self, lengths):
         """The captured pass ran on a RAGGED batch (utterances of `lengths` frames stacked along time in one image): the decisions
@@ -85,19 +98,33 @@ class DecisionCapture:
         """{'convXY': bool [B,C,H,W], 'poolX': int64 [B,C,Ho,Wo]} on the CPU, real channels only (the zero-padded network of a
         narrow kernel_size carries pad channels that are identically zero)."""
         fe = self.fe
-        events = self.events if events is None else events
-        names = []
-        for blk in range(1, fe.n_blocks + 1):
-            names += [("conv", "conv%d1" % blk), ("conv", "conv%d2" % blk), ("pool", "pool%d" % blk)]
-        assert [k for k, _ in events] == [k for k, _ in names], [k for k, _ in events]
+        it = iter(self.events if events is None else events)
         out = {}
-        c = None
-        for (kind, name), (_, t) in zip(names, events):
-            if kind == "conv":
-                c = getattr(fe, name).out_channels
-                out[name] = (t[:, :c] > 0).cpu()
-            else:
-                # ATen's arg-max (first maximum in window order) is the kernels' own tie-breaking: bit-exact pools are tested in
-                # test_hip_maxpool_and_conv11_backward_match_torch
-                out[name] = F.max_pool2d(t[:, :c].contiguous(), 2, stride=2, ceil_mode=True, return_indices=True)[1].cpu()
+        for blk in range(1, fe.n_blocks + 1):
+            n1, n2, pn = "conv%d1" % blk, "conv%d2" % blk, "pool%d" % blk
+            kind, t = next(it)
+            assert kind == "conv", kind
+            out[n1] = (t[:, :getattr(fe, n1).out_channels] > 0).cpu()
+            kind, t = next(it)
+            c = getattr(fe, n2).out_channels
+            if kind == "convpool":
+                code, H, W = t
+                code = code.cpu().permute(0, 3, 1, 2)[:, :c].long()                     # [B, C, Ho, Wo]
+                Ho, Wo = code.shape[2], code.shape[3]
+                ho = torch.arange(Ho).view(1, 1, Ho, 1)
+                wo = torch.arange(Wo).view(1, 1, 1, Wo)
+                pos = code & 3
+                out[pn] = (2 * ho + (pos >> 1)) * W + 2 * wo + (pos & 1)
+                # the ReLU's sign is known for the element each window hands on (nothing else of that map has any effect)
+                mask = torch.zeros(code.shape[0], c, H * W, dtype=torch.bool)
+                out[n2] = mask.scatter_(2, out[pn].flatten(2), (code & 4).flatten(2) > 0).view(code.shape[0], c, H, W)
+                continue
+            assert kind == "conv", kind
+            out[n2] = (t[:, :c] > 0).cpu()
+            kind, t = next(it)
+            assert kind == "pool", kind
+            # ATen's arg-max (first maximum in window order) is the kernels' own tie-breaking: bit-exact pools are tested in
+            # test_hip_maxpool_and_conv11_backward_match_torch
+            out[pn] = F.max_pool2d(t[:, :c].contiguous(), 2, stride=2, ceil_mode=True, return_indices=True)[1].cpu()
+        assert next(it, None) is None
         return out

@@ -538,6 +538,36 @@ def test_data_parallel_trainer_single_rank_matches_plain_optimizer_step():
     assert float(tr.reducer.flat.abs().sum()) == 0.0     # gradients cleared for the next step
 
 
+def test_a_fused_optimizer_step_is_seen_by_the_next_forward():
+    """torch's fused optimizers (`Adam(..., fused=True)`, what DataParallelTrainer uses on the GPU) update the parameters WITHOUT
+    moving their version counters, which the cache of packed convolution weights is keyed by: a training forward therefore packs
+    the planes from the parameters it is handed, every time, and a no-grad forward after the step must see the new weights too.
+    Three steps of train.py:215-226 with a large learning rate; after every step the front-end's output (training forward and
+    no-grad forward) must equal the output of a FRESH module loaded with the current state_dict."""
+    from doubleattentionspeakerverification_amd.CNNs import VGG4L
+    torch.manual_seed(5)
+    net = VGG4L(128).to(DEV).train()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-2, fused=True)
+    x = torch.from_numpy(rnd(77, 3, 40, 80)).to(DEV)
+    with torch.no_grad():
+        before = net(x).clone()          # (leaves cached planes behind: they must not survive the step)
+    for step in range(3):
+        v0 = net.conv21.weight._version
+        net(x).square().mean().backward()
+        opt.step()
+        opt.zero_grad()
+        fresh = VGG4L(128).to(DEV).train()
+        fresh.load_state_dict(net.state_dict())
+        want = fresh(x).detach()
+        assert float((want - before).abs().max()) > 1e-3 * float(before.abs().max())      # the step moved the output
+        with torch.no_grad():
+            got_eval = net(x)
+        got_train = net(x).detach()
+        scale = float(want.abs().max())
+        assert float((got_eval - want).abs().max()) <= 2e-5 * scale, (step, net.conv21.weight._version - v0)
+        assert float((got_train - want).abs().max()) <= 2e-5 * scale, step
+
+
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 64, 9, 7, 3), (128, 64, 38, 10, 5), (64, 128, 33, 80, 2), (64, 64, 1, 1, 2),
                                            (128, 128, 19, 5, 7), (64, 64, 13, 8, 3), (128, 64, 10, 24, 2), (64, 64, 8, 40, 2)])
 def test_hip_conv3x3_wgrad_vs_fp64(cin, cout, H, W, B):

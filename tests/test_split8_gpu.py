@@ -294,16 +294,38 @@ def test_narrow_kernel_size_training_gradients_vs_float64_under_the_same_decisio
         assert err < 2e-4, (k, err)          # of the tensor's scale; split8 products are ~1e-5 per layer
 
 
+@pytest.mark.parametrize("cout,cin", [(128, 64), (64, 128), (256, 128), (128, 384)])
+def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin):
+    """dasv_conv3x3_pack_weights_x8_dgrad: the split8 planes of a layer's data-gradient convolution (train.py:220; the weights
+    transposed over (out, in) and flipped over (ky, kx)) packed straight from the layer's weight must be the planes
+    dasv_conv3x3_pack_weights_x8 makes from an explicitly transposed and flipped copy — byte for byte (fp16 plane, e4m3 planes, scale
+    bytes, channel scales); the L1 bound behind them is summed in another order (last-bit differences)."""
+    from doubleattentionspeakerverification_amd import conv
+    w = torch.from_numpy(rnd(17, cout, cin, 3, 3, scale=0.05)).to(DEV)
+    w[3, 5] *= 1e4                                      # channels of very different magnitude: per-channel scales
+    w[:, 7] *= 1e-6
+    hi, lo = conv._pack_dgrad_x8(w)
+    hi2, lo2 = conv.PackedConvWeights().get(w.transpose(0, 1).flip(2, 3).contiguous(), "split8")
+    n_planes = cin * 9 * cout * 2
+    assert torch.equal(hi[:n_planes], hi2[:n_planes])
+    body = n_planes + cin * 8                           # e4m3 planes | [cin][4] scale bytes | [cin] floats 2^-Ew
+    assert torch.equal(lo[:body], lo2[:body])
+    t1, t2 = lo[body:body + 8].view(torch.float32), lo2[body:body + 8].view(torch.float32)
+    assert abs(float(t1[0]) - float(t2[0])) <= 1e-5 * float(t2[0]) and float(t1[1]) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 9, 7, 3), (128, 128, 38, 10, 5), (64, 128, 33, 80, 2), (64, 128, 1, 1, 2),
                                            (128, 128, 19, 5, 7), (64, 256, 13, 8, 3), (128, 128, 10, 24, 2), (64, 128, 8, 40, 2),
-                                           (256, 128, 75, 20, 2)])
+                                           (256, 128, 75, 20, 2), (128, 128, 17, 48, 2), (64, 256, 16, 64, 3), (64, 128, 150, 40, 9)])
 def test_split8_masked_data_gradient_vs_fp64(cin, cout, H, W, B):
     """dasv_conv3x3_masked_x8_nhwc — the DATA gradient of the shipped training default (train.py:220 through
     `F.relu(convX2(F.relu(convX1(h))))`, CNNs.py:72-86): g [B,H,W,cin] = the gradient at the upper layer's output, weights = the
     upper layer's transposed and flipped, mask = the lower layer's ReLU output, y = conv(g) where mask > 0 — against a float64
     convolution times (mask > 0).  Gradient scales 1e-7 ... 1e5 (real ones are ~1e-8 ... 1e-2), a heavy-tailed gradient, a
     record that is measured and one that only bounds the maximum, the output's record, and the per-channel column sums (the bias
-    gradient of the layer below).  Bound: 4e-5 of the output scale, the forward mode's."""
+    gradient of the layer below).  Bound: 4e-5 of the output scale, the forward mode's.  Maps of 80 / 64 / 48 columns run on PATCH
+    tiles (heights that are no multiple of 16: patches that hang over the image), the others on 256- / 192-pixel raster tiles; all of
+    them apply the mask and form the column sums in the coalescing write-out pass."""
     from doubleattentionspeakerverification_amd import conv
     g0 = torch.from_numpy(rnd(91, B, cin, H, W)).to(DEV).contiguous(memory_format=torch.channels_last)
     w = torch.from_numpy(rnd(92, cin, cout, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)     # the upper layer: cout -> cin
@@ -335,6 +357,52 @@ def test_split8_masked_data_gradient_vs_fp64(cin, cout, H, W, B):
     reft = _conv64(gt, wt) * keep
     gott = conv._launch(gt, hi, lo, None, cout, "split8", relu=0, mask=mask)
     assert float((gott.cpu().double() - reft).abs().max()) / float(reft.abs().max()) < 6.2e-5
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 37, 80, 3), (128, 128, 75, 40, 4), (64, 128, 38, 20, 9), (128, 256, 19, 10, 16),
+                                           (64, 128, 7, 33, 4)])
+def test_training_conv_relu_pool_in_one_launch_equals_the_two_node_form(cin, cout, H, W, B):
+    """conv.conv3x3_bias_relu_pool (dasv_conv3x3_bias_relu_pool_idx_x8_nhwc: pooled map + arg-max bytes, no full-resolution map;
+    CNNs.py:73-74 in training, train.py:215-220) against the two autograd nodes it replaces — conv3x3_bias_relu(grad_premasked) +
+    maxpool2x2_ceil_autograd(relu_input): same convolution arithmetic and the same arg-max rule, so the pooled map, the input
+    gradient (with the lower layer's ReLU mask fused), the weight gradient and the bias gradient must be IDENTICAL; and against
+    float64 autograd of the reference's expression."""
+    from doubleattentionspeakerverification_amd import conv
+    if not conv.pool_fusable("split8", B, H, W, cin, cout):
+        pytest.skip("no one-launch form for this shape")
+    x0 = torch.relu(torch.from_numpy(rnd(31, B, cin, H, W))).to(DEV).contiguous(memory_format=torch.channels_last)
+    w0 = torch.from_numpy(rnd(32, cout, cin, 3, 3, scale=(2.0 / (9 * cin)) ** 0.5)).to(DEV)
+    b0 = torch.from_numpy(rnd(33, cout, scale=0.1)).to(DEV)
+    gout = torch.from_numpy(rnd(34, B, cout, (H + 1) // 2, (W + 1) // 2)).to(DEV).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        link = {}
+        if fused:
+            y = conv.conv3x3_bias_relu_pool(x, w, b, mask_input_grad=True, link_out=link)
+        else:
+            l2 = {}
+            h = conv.conv3x3_bias_relu(x, w, b, None, "split8", True, True, l2, link)
+            y = conv.maxpool2x2_ceil_autograd(h, relu_input=True, link_out=l2)
+        y.backward(gout)
+        # (link: the per-channel sums of the masked input gradient = the bias gradient of the layer below — left behind when the
+        # layer's data gradient runs un-padded, 128-multiples of input channels)
+        res.append((y.detach(), x.grad, w.grad, b.grad, link.get("gb", torch.zeros(1, device=DEV))))
+    assert ("gb" in link) == (cin % 128 == 0)
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    x, w, b = x0.double().cpu().requires_grad_(True), w0.double().cpu().requires_grad_(True), b0.double().cpu().requires_grad_(True)
+    y64 = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(x, w, b, padding=1)), 2, stride=2, ceil_mode=True)
+    y64.backward(gout.double().cpu())
+    y, gx, gw, gb, _ = res[0]
+    assert _rel(y.cpu(), y64.detach()) < 4e-5
+    # The bias gradient does not depend on WHICH element a window hands on.  The input and weight gradients do — a window whose two
+    # largest values agree to ~1e-5 may hand on the other one, and on this random data ONE such window moves entries of both by
+    # percents — so against float64 they are held under the same decisions elsewhere (test_model_gpu.py: fixture G7, the
+    # variable-length steps; test_narrow_kernel_size_training_gradients_vs_float64_under_the_same_decisions), all of which run this
+    # one-launch form; here: identity with the two-node form above, and sanity of the scale
+    assert _rel(gb.cpu(), b.grad) < 2e-4
+    assert _rel(gw.cpu(), w.grad) < 0.2 and float((gx.cpu().double() - x.grad * (x0.cpu() > 0)).abs().mean() / x.grad.abs().mean()) < 0.05
 
 
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 37, 80, 3), (64, 128, 38, 80, 2), (64, 256, 75, 40, 3), (128, 128, 150, 40, 16),
