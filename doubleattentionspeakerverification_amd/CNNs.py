@@ -89,6 +89,10 @@ class _VGG(nn.Module):
         # training (split8): the same one-launch form of convX2 + ReLU + pool (conv.conv3x3_bias_relu_pool) for these blocks — the
         # launch also writes the pool's arg-max bytes, which is all the backward needs of the full-resolution map
         self.fuse_pool_training = {1, 2, 3, 4}
+        # training (split8, dense batches, exact channel counts): EVERY activation of the forward pass in the packed operand form (the
+        # inference chain plus the pools' arg-max bytes; only the last pooled map is fp32) — the next layer's staging, the weight
+        # gradient's producers and the data gradient's mask read all take the packed form as it is (_forward_map_packed_train)
+        self.packed_training = True
         self._packed = {}
 
     def _mode(self):
@@ -203,6 +207,56 @@ class _VGG(nn.Module):
             rh = ry
         return h
 
+    def _packed_training_ok(self, fdim, batch, frames):
+        """The packed training chain exists when the packed inference chain does (_packed_chain_ok), every convolution's input
+        channels are a multiple of 128 (its data gradient then runs un-padded) and every block's convX2 + pool has its one-launch
+        form."""
+        if not self._packed_chain_ok(fdim, batch, frames):
+            return False
+        H, W = frames, fdim
+        for blk in range(1, self.n_blocks + 1):
+            c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
+            for c in (c1, c2):
+                if c is self.conv11:
+                    continue
+                if c.in_channels % 128 != 0:
+                    return False
+            if not _hipconv.pool_fusable("split8", batch, H, W, c2.in_channels, c2.out_channels):
+                return False
+            H, W = (H + 1) // 2, (W + 1) // 2
+        cp = self.conv11.out_channels
+        return cp % 128 == 0 and (cp & (cp - 1)) == 0 and cp <= 1024       # conv11 writes the packed form for these widths
+
+    def _forward_map_packed_train(self, x):
+        """The training forward on packed activations: conv11 -> PACKED -> conv12 + pool (+ arg-max bytes) -> PACKED -> convX1 ->
+        PACKED -> convX2 + pool -> ... -> fp32 map; every node's backward reads the packed tensors directly (conv.conv3x3_bias_relu,
+        conv.conv3x3_bias_relu_pool with x_packed / y_packed).  Same values as _forward_map_packed."""
+        dev = x.device
+        x = x.contiguous()
+        r = iter(_hipconv.new_ranges(dev, 1 + 2 * self.n_blocks))
+        rx = next(r)
+        _lib = _hipconv._lib
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dasv_range_absmax_f32")
+        rh = next(r)
+        h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, pack=True, x_rec=rx)
+        for blk in range(1, self.n_blocks + 1):
+            n1, n2 = "conv%d1" % blk, "conv%d2" % blk
+            c1, c2 = getattr(self, n1), getattr(self, n2)
+            l1 = {}
+            if blk > 1:
+                ry = next(r)
+                h = _hipconv.conv3x3_bias_relu(h, c1.weight, c1.bias, self._pk(n1, dev), "split8", grad_premasked=True, link_in=l1,
+                                               x_rec=rh, y_rec=ry, x_packed=True, y_packed=True)
+                rh = ry
+            ry = next(r)
+            h = _hipconv.conv3x3_bias_relu_pool(h, c2.weight, c2.bias, self._pk(n2, dev), mask_input_grad=True,
+                                                link_out=None if blk == 1 else l1,       # conv11's kernel sums its own bias gradient
+                                                x_rec=rh, y_rec=ry, x_packed=True, y_packed=blk < self.n_blocks)
+            rh = ry
+        return h
+
     def _forward_map_f16(self, x):
         """The same chain with HALF-PRECISION tensors between the layers (fp16-operand mode, inference): conv11 -> f16 -> conv12 ->
         f16 -> pool -> f16 -> ... -> convN2 -> f16 -> last pool -> fp32 map.  Every tensor holds v * 2^E, E from its range record
@@ -282,6 +336,9 @@ class _VGG(nn.Module):
             _hipconv.invalidate_packed_weights(self)
         if hip and not grad and self.packed_activations and self._mode() == "split8" and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_packed(paddedInputTensor)
+        if (hip and grad and tables is None and self.packed_training and self._mode() == "split8" and not paddedInputTensor.requires_grad
+                and self._packed_training_ok(Fdim, B, T)):
+            return self._forward_map_packed_train(paddedInputTensor)
         if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
                 and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_f16(paddedInputTensor)

@@ -181,12 +181,14 @@ def _rec_of(t):
     return tagged[0]
 
 
-def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None, span=None):
+def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=None, y_rec=None, span=None, x_packed=False, y_packed=False,
+            mask_packed=False):
     """colsum (with mask): a dict that receives 'gb' = per-channel sums of the masked output (fixed-order partial sums
     from the kernel's epilogue, then one small sum) when the map is narrow enough for the window kernel.
     x_rec / y_rec (split8): range records of x (made here by a pass over x when the caller has none) and of y (optional).
     span (split8): x is a RAGGED batch — utterances of different lengths stacked along H in one image [1, C, rows, W] — and span
-    its border table (ragged.ragged_tables): taps never cross from one utterance into the next."""
+    its border table (ragged.ragged_tables): taps never cross from one utterance into the next.
+    x_packed / y_packed / mask_packed (split8, dense batches): that tensor is a PACKED activation tensor (conv3x3_x8)."""
     lib = _lib.load()
     B, cin, H, W = x.shape
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -214,9 +216,25 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                                                                None if ws is None else ws.data_ptr(), nws, H, W, cin, cout, relu, stream)
         _lib.check(rc, "dasv_conv3x3_*_ragged_x8_nhwc")
         return y
+    if (x_packed or y_packed or mask_packed) and (mode != "split8" or span is not None):
+        raise RuntimeError("packed activation tensors belong to the split8 mode on dense batches")
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if mode == "split8" and mask is not None:
+        if mode == "split8" and (x_packed or y_packed) and mask is None:
+            rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                    None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
+                                                    None if y_rec is None else y_rec.data_ptr(), None, 0, B, H, W, cin, cout, relu, stream)
+        elif mode == "split8" and mask is not None and mask_packed:
+            rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0) if colsum is not None else 0
+            part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
+            nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout) if part is None else 0      # (column sums: one pass)
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+            rc = lib.dasv_conv3x3_masked_x8p_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
+                                                  None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
+                                                  None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, stream)
+            if part is not None and rc == 0:
+                colsum["gb"] = part.sum(dim=0)
+        elif mode == "split8" and mask is not None:
             rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0) if colsum is not None else 0
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             rc = lib.dasv_conv3x3_masked_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
@@ -255,7 +273,7 @@ def supported_wgrad(cin, cout, width=1, pixels=0):
     return cin % 64 == 0 and cout % 64 == 0 and width <= 80 and pixels * max(cin, cout) * 4 < 0xffffffff
 
 
-def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
+def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_packed=False):
     """Weight gradient [Cout,Cin,3,3] of conv3x3 (stride 1, pad 1) from x [B,Cin,H,W] and g [B,Cout,H,W]
     (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip).
     mode "split8": fp16 products + block-scaled e4m3 cross terms; x_rec / g_rec are the operands' range records (an upper bound
@@ -263,7 +281,11 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
     borders (ragged batch: x / g are utterances stacked along H in one image, B == 1): int64 tensor of the first rows of the
     utterances 1 ... n-1.  The launch on the stacked image also multiplies across every border — g of an utterance's first row with x of
     the previous utterance's last row (taps ky = 0) and g of a last row with x of the next first row (ky = 2); exactly those products
-    are computed a second time from 2-row images {last row | first row} and subtracted."""
+    are computed a second time from 2-row images {last row | first row} and subtracted.
+    x_packed (split8, dense): x is a PACKED activation tensor and x_rec the record its producer filled — the kernel's producer waves
+    then copy instead of converting (dasv_conv3x3_wgrad_x8p_nhwc)."""
+    if x_packed and (mode != "split8" or x_rec is None or borders is not None):
+        raise RuntimeError("a packed x operand: split8 mode, dense batch, with the record its producer filled")
     if borders is not None and borders.numel() > 0:
         if x.shape[0] != 1:
             raise RuntimeError("a ragged batch is one stacked image")
@@ -291,8 +313,9 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
         x_rec = range_of(x) if x_rec is None else x_rec
         g_rec = range_of(g) if g_rec is None else g_rec
         with torch.cuda.device(x.device):
-            rc = lib.dasv_conv3x3_wgrad_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), g_rec.data_ptr(), gw.data_ptr(), ws.data_ptr(),
-                                                nbytes, B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
+            fn = lib.dasv_conv3x3_wgrad_x8p_nhwc if x_packed else lib.dasv_conv3x3_wgrad_x8_nhwc
+            rc = fn(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), g_rec.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+                    nbytes, B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_wgrad_x8_nhwc")
         return gw
     with torch.cuda.device(x.device):
@@ -305,7 +328,7 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None):
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span=None, borders=None,
-                fresh=False):
+                fresh=False, x_packed=False, y_packed=False):
         # x carries cin_x >= Cin channels (a multiple of 64; the surplus is zero) and y gets padded_channels(Cout): the layer runs
         # as its zero-padded form (see `supported`)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -314,8 +337,11 @@ class _ConvReLUFn(torch.autograd.Function):
         bias_k = packed.bias if (cin_x, cout_p) != (cin, cout) and bias is not None else bias
         if mode == "split8" and x_rec is None:
             x_rec = range_of(x)
-        y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec, span=span)
+        if y_packed and not grad_premasked:
+            raise RuntimeError("a packed output's ReLU mask is applied by its consumer (grad_premasked)")
+        y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec, span=span, x_packed=x_packed, y_packed=y_packed)
         ctx.span, ctx.borders = span, borders           # ragged batch (one stacked image): border tables of this level
+        ctx.x_packed = x_packed
         ctx.save_for_backward(x, weight, y)
         ctx.x_rec = x_rec           # (split8) the weight gradient scales x by the same record
         ctx.has_bias = bias is not None
@@ -331,7 +357,7 @@ class _ConvReLUFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         # ReLU backward in one pass (g = gy where y > 0 else 0) — unless the consumer of y already applied it
         g = gy if ctx.grad_premasked else torch.ops.aten.threshold_backward(gy, y, 0.0)
-        return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1]) + (None,) * 11
+        return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1]) + (None,) * 13
 
 
 def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
@@ -355,8 +381,11 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
         # (the kernel writes 128-channel tiles: an input with a 64-multiple of channels gets its gradient through a padded
         # transposed layer and a slice — narrow kernel sizes only)
         n_out = (cin_x + 127) // 128 * 128
-        if dmode == "split8" and not padded and n_out == cin_x and weight.dtype == torch.float32 and weight.is_contiguous():
-            hi, lo = _pack_dgrad_x8(weight.detach())      # straight from the layer's weight: no transposed copy
+        if (dmode == "split8" and not padded and n_out == cin_x and weight.dtype == torch.float32 and weight.is_contiguous()
+                and cin * cout <= 256 * 256):
+            # straight from the layer's weight, no transposed copy: one launch instead of four for the small layers (measured:
+            # 8-22 us against 25-35); its strided reads lose on the large ones (conv42: 215 us against 116 for flip + copy + pack)
+            hi, lo = _pack_dgrad_x8(weight.detach())
         else:
             wt = weight.detach()
             if padded or n_out != cin_x:
@@ -368,10 +397,13 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
             # mask_input_grad: x is the ReLU output of the layer below (its only consumer is this layer), so that ReLU's
             # backward is applied in this kernel's epilogue
             gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
-                         colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span)
+                         colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span,
+                         mask_packed=ctx.x_packed and ctx.mask_input_grad)
             if gx_rec is not None:
                 _attach_rec(gx, gx_rec)
         else:
+            if ctx.x_packed:
+                raise RuntimeError("packed training chain: input channels must be a multiple of 128")
             gx = _launch(g, hi, lo, None, n_out, dmode, relu=0, x_rec=g_rec, span=ctx.span)[:, :cin_x].contiguous(memory_format=torch.channels_last)
             if ctx.mask_input_grad:
                 gx = torch.ops.aten.threshold_backward(gx, x, 0.0)
@@ -381,7 +413,8 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
         wmode = WGRAD_MODE[ctx.mode]
         # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
         gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
-                           g_rec=g_rec_in if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None)
+                           g_rec=g_rec_in if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None,
+                           x_packed=ctx.x_packed)
         if padded:
             gw = gw[:cout, :cin].contiguous()
         want_w = False
@@ -392,8 +425,8 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
                 gb = g.sum(dim=(0, 2, 3))
             gb = gb[:cout] if padded else gb
             want_b = False
-    if (want_x or want_w or want_b) and ctx.span is not None:
-        raise RuntimeError("ragged training batch: a gradient fell outside the hand-written kernels' limits (operands beyond 4 GB?)")
+    if (want_x or want_w or want_b) and (ctx.span is not None or ctx.x_packed):
+        raise RuntimeError("ragged / packed training batch: a gradient fell outside the hand-written kernels' limits (operands beyond 4 GB?)")
     if want_x or want_w or want_b:
         # (maps wider than 80 columns / operands beyond 4 GB only: the weight-gradient kernel's limits)
         wfull = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, cin_x - cin, 0, cout_p - cout)) if padded else weight
@@ -414,7 +447,7 @@ class _ConvReLUPoolFn(torch.autograd.Function):
     behind), then runs the layer's weight- and data-gradient launches; the full-resolution activation map never exists."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, mask_input_grad, link_out, x_rec, y_rec, fresh=True):
+    def forward(ctx, x, weight, bias, packed, mask_input_grad, link_out, x_rec, y_rec, fresh=True, x_packed=False, y_packed=False):
         lib = _lib.load()
         cout, cin = weight.shape[0], weight.shape[1]
         B, cin_x, H, W = x.shape
@@ -425,8 +458,8 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         idx = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                                             None if bias is None else bias.data_ptr(), y.data_ptr(),
+            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                             None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
                                                              None if y_rec is None else y_rec.data_ptr(), idx.data_ptr(), B, H, W, cin_x, cout,
                                                              torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
@@ -435,6 +468,7 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         ctx.grad_premasked, ctx.mask_input_grad = True, mask_input_grad
         ctx.link_in, ctx.link_out = {}, link_out
         ctx.span = ctx.borders = None
+        ctx.x_packed = x_packed
         return y
 
     @staticmethod
@@ -454,23 +488,28 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         if part is not None:
             ctx.link_in["gb"] = part.sum(dim=0)
         # (the scattered gradient's range record is its source's: max |g| <= max |gy|)
-        return _conv_backward(ctx, x, weight, g, _rec_of(gy), C) + (None,) * 6
+        return _conv_backward(ctx, x, weight, g, _rec_of(gy), C) + (None,) * 8
 
 
-def conv3x3_bias_relu_pool(x, weight, bias, packed=None, mask_input_grad=False, link_out=None, x_rec=None, y_rec=None):
+def conv3x3_bias_relu_pool(x, weight, bias, packed=None, mask_input_grad=False, link_out=None, x_rec=None, y_rec=None, x_packed=False,
+                           y_packed=False):
     """Differentiable `max_pool2d(relu(conv2d(x, weight, bias, padding 1)), 2, stride=2, ceil_mode=True)` in the split8 mode for shapes
     `pool_fusable("split8", ...)` accepts (x [B,Cin,H,W] channels_last fp32): one forward launch, no full-resolution map.
-    mask_input_grad / link_out / x_rec / y_rec as in conv3x3_bias_relu."""
+    mask_input_grad / link_out / x_rec / y_rec / x_packed / y_packed as in conv3x3_bias_relu (y: the pooled map)."""
     if not x.is_cuda or x.dtype != torch.float32:
         raise RuntimeError("conv3x3_bias_relu_pool runs on fp32 GPU tensors only (libdasv_hip.so); no CPU fallback")
+    if (x_packed and (x_rec is None or weight.shape[1] % 128 != 0)) or (y_packed and y_rec is None):
+        raise RuntimeError("packed activations: Cin % 128 == 0 and the range records of the packed tensors")
     if not x.is_contiguous(memory_format=torch.channels_last):
+        if x_packed:
+            raise RuntimeError("a packed activation tensor must keep its channels_last layout")
         x = x.contiguous(memory_format=torch.channels_last)
     fresh = torch.is_grad_enabled() and weight.requires_grad
-    return _ConvReLUPoolFn.apply(x, weight, bias, packed or PackedConvWeights(), mask_input_grad, link_out, x_rec, y_rec, fresh)
+    return _ConvReLUPoolFn.apply(x, weight, bias, packed or PackedConvWeights(), mask_input_grad, link_out, x_rec, y_rec, fresh, x_packed, y_packed)
 
 
 def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
-                      link_in=None, link_out=None, x_rec=None, y_rec=None, span=None, borders=None):
+                      link_in=None, link_out=None, x_rec=None, y_rec=None, span=None, borders=None, x_packed=False, y_packed=False):
     """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
 
     Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
@@ -486,6 +525,10 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     span / borders (training on a RAGGED batch, split8): x is [1, C, rows, W] — utterances of different lengths stacked along H — with
     its border table (ragged.ragged_tables) and the first rows of utterances 1 ... n-1 (int64): forward, data gradient and weight
     gradient then treat every utterance as its own image.
+    x_packed / y_packed (training on PACKED activations, split8, dense batches, exact channel counts with Cin % 128 == 0): x and / or
+    the result are packed activation tensors (conv3x3_x8) with their records in x_rec / y_rec — the weight gradient then reads x
+    without converting it and the data-gradient kernel takes the ReLU mask from x's fp16 plane; a packed result requires
+    grad_premasked (its consumer applies the mask).
     Channel counts that are not multiples of (64, 128): x may carry more channels than the layer has inputs (zeros), and the
     result carries padded_channels(Cout) channels, the surplus identically zero (see `supported`); slice when needed."""
     if not x.is_cuda:
@@ -497,6 +540,10 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
         # the caller's tensor has the layer's own (non-multiple-of-64) channel count: zero-pad it (one pass over x; the VGG
         # front-end keeps its activations padded between the layers instead, CNNs.py)
         x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, (cin + 63) // 64 * 64 - x.shape[1]))
+    if x_packed or y_packed:
+        if (mode != "split8" or x.shape[3] > 80 or not exact(cin, weight.shape[0]) or cin % 128 != 0 or x.shape[1] != cin
+                or (x_packed and x_rec is None) or (y_packed and y_rec is None) or not x.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError("packed activations: split8 mode, maps up to 80 columns, exact channel counts (Cin % 128 == 0), range records")
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     if mode == "split8" and x.shape[3] > 80:
@@ -506,7 +553,8 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     # (a training pass — the weight's gradient is being recorded — packs the planes afresh: PackedConvWeights; decided here because
     # grad mode is off inside an autograd Function's forward and ctx.needs_input_grad ignores torch.no_grad())
     fresh = torch.is_grad_enabled() and weight.requires_grad
-    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders, fresh)
+    return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders, fresh,
+                             x_packed, y_packed)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
@@ -775,9 +823,11 @@ class _Conv11ReLUFn(torch.autograd.Function):
     """relu(conv2d(x[:,None], w, b, padding 1)) for x [B,H,W] (no gradient w.r.t. x: x is the input feature map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, y_rec, grad_premasked=False, span=None):
+    def forward(ctx, x, weight, bias, y_rec, grad_premasked=False, span=None, pack=False, x_rec=None):
+        if pack and (span is not None or not grad_premasked):
+            raise RuntimeError("a packed first-layer output: dense batches, ReLU mask applied by the consumer")
         if span is None:
-            y = conv3x3_c1_bias_relu(x, weight, bias, y_rec=y_rec)
+            y = conv3x3_c1_bias_relu(x, weight, bias, pack=pack, x_rec=x_rec, y_rec=y_rec)
         else:      # ragged batch: x [1, rows, W], utterances stacked along the rows, borders from `span`
             lib = _lib.load()
             x = x.contiguous()
@@ -820,11 +870,11 @@ class _Conv11ReLUFn(torch.autograd.Function):
                                                          gw.data_ptr(), None if gb is None else gb.data_ptr(), ws.data_ptr(), nbytes,
                                                          ctx.span.data_ptr(), H, W, cout, torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(rc, "dasv_conv3x3_c1_bwd_nhwc")
-        return None, gw, gb, None, None, None
+        return None, gw, gb, None, None, None, None, None
 
 
-def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None, grad_premasked=False, span=None):
+def conv3x3_c1_bias_relu_autograd(x, weight, bias, y_rec=None, grad_premasked=False, span=None, pack=False, x_rec=None):
     """Differentiable (w.r.t. weight and bias) first layer on the HIP kernels; x [B,H,W] must not require grad.
     grad_premasked: the one consumer of the result applies this layer's ReLU mask to the gradient it sends back (a following
     conv3x3_bias_relu(..., mask_input_grad=True)), so the backward reads that gradient only."""
-    return _Conv11ReLUFn.apply(x, weight, bias, y_rec, grad_premasked, span)
+    return _Conv11ReLUFn.apply(x, weight, bias, y_rec, grad_premasked, span, pack, x_rec)

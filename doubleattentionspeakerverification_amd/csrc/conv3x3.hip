@@ -248,6 +248,7 @@ struct ConvParams {
     const uint16_t* wlo;
     const float* bias;     // [Cout] or null
     const float* mask;     // [B,H,W,Cout] or null: outputs are zeroed where mask <= 0 (a ReLU's backward, fused)
+    int mask_packed;       // mask is a PACKED activation tensor (dasv_common.hpp): the sign is read from its fp16 plane (pipelined launches)
     float* colsum;         // [mtiles][Cout] or null (window kernel): per-channel sums of the stored tile (bias gradients)
     const int* row_span;   // ragged batch (B == 1, H == total rows): [H][2] = first / one-past-last row of the utterance
                            // that owns each row; image borders come from this table instead of row % H
@@ -1486,7 +1487,17 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     if (k0 + k >= TBM / 16) m = p.M;
                     mm[k] = m;
                     mk[k] = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (p.mask != nullptr && m < p.M) mk[k] = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n0 + col * 4);
+                    if (p.mask != nullptr && m < p.M) {
+                        if (p.mask_packed) {      // four halves of the pixel's fp16 plane (c = v * 2^E: the same sign)
+                            const int n = n0 + col * 4;
+                            const uint2 hb = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.mask) + (size_t)m * p.Cout * 4 +
+                                                                             (n >> 6) * 256 + (n & 63) * 2);
+                            const f16x2_t a = __builtin_bit_cast(f16x2_t, hb.x), b2 = __builtin_bit_cast(f16x2_t, hb.y);
+                            mk[k] = f32x4{(float)a[0], (float)a[1], (float)b2[0], (float)b2[1]};
+                        } else {
+                            mk[k] = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.Cout + n0 + col * 4);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
@@ -1572,7 +1583,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 // y = f(sum_ks part[ks] + bias): the second launch of a split-K convolution (fixed summation order)
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias,
                                                              const float* __restrict__ mask, float* __restrict__ y,
-                                                             long long nvec, int Cout, int S, int relu, uint32_t* __restrict__ y_rec) {
+                                                             long long nvec, int Cout, int S, int relu, uint32_t* __restrict__ y_rec,
+                                                             int mask_packed) {
     const long long plane = nvec * 4;
     uint32_t amax_u = 0u;
     __shared__ uint32_t s_amax;
@@ -1584,7 +1596,15 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce(const float* __rest
         if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + (int)((i * 4) % Cout));
         if (relu) v = f32x4{relu_nan(v[0]), relu_nan(v[1]), relu_nan(v[2]), relu_nan(v[3])};
         if (mask != nullptr) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
+            f32x4 mk;
+            if (mask_packed) {       // a packed activation tensor: the sign of the fp16 plane (four halves of the pixel's slab)
+                const int n = (int)((i * 4) % Cout);
+                const uint2 hb = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(mask) + (i * 4 - n) * 4 + (n >> 6) * 256 + (n & 63) * 2);
+                const f16x2_t a = __builtin_bit_cast(f16x2_t, hb.x), b2 = __builtin_bit_cast(f16x2_t, hb.y);
+                mk = f32x4{(float)a[0], (float)a[1], (float)b2[0], (float)b2[1]};
+            } else {
+                mk = *reinterpret_cast<const f32x4*>(mask + i * 4);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
         }
@@ -1690,7 +1710,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
                           const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, const uint32_t* x_rec = nullptr,
-                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr) {
+                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr, int mask_packed = 0) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
@@ -1706,14 +1726,16 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.part = nullptr; p.ksplit = 1;
     p.x_packed = x_packed; p.y_packed = y_packed;
     p.x_rec = x_rec; p.y_rec = y_rec;
-    if ((x_packed || y_packed) && (mask != nullptr || colsum != nullptr || mel != nullptr)) return DASV_E_SHAPE;
+    p.mask_packed = mask_packed;
+    if (y_packed && (mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
+    if ((x_packed || y_packed) && mel != nullptr) return DASV_E_SHAPE;
     if ((x_packed == 1 || y_packed == 1) && mode != 3) return DASV_E_SHAPE;        // packed split8 planes
     if ((x_packed == 2 || y_packed == 2) && (mode != 2 || W > 80)) return DASV_E_SHAPE;   // fp16 tensors: the fp16-operand window kernel
     if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
     if ((x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
     p.row_span = row_span;
     p.pool = 0; p.pool_units = 0; p.pool_U = 0; p.pool_idx = pool_idx;
-    if (pool_idx != nullptr && (!pool || y_packed)) return DASV_E_SHAPE;
+    if (pool_idx != nullptr && !pool) return DASV_E_SHAPE;
     if (row_span != nullptr && (B != 1 || W > 80 || mel != nullptr)) return DASV_E_SHAPE;   // ragged: one tall image, window kernel
     // fused max-pool: dense batches, plain epilogue (no mask / column sums / split-K), relu'd outputs
     if (pool && (row_span != nullptr || mask != nullptr || colsum != nullptr || mel != nullptr || W > 80 || !relu)) return DASV_E_SHAPE;
@@ -1736,6 +1758,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         // both tile buffers (stride 32 KB also for the one-plane modes) whenever they fit: the launch then runs the pipelined loops
         // (round 1 measured the double buffer alone as a loss for bf16 operands — with the un-pipelined loop)
         const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
+        // (a packed mask is read by the pipelined launches' write-out pass or by the split-K reduction)
+        if (mask_packed && S == 1 && !dbuf) return DASV_E_SHAPE;
         // patch tiles (GEOM = 1): maps whose width is a multiple of 16 and whose raster window would be larger than the 18 x 18
         // patch window (80 / 64 / 48 columns; the 80-column first block in this model) — pipelined split8 launches (forward and
         // masked data gradient) without ragged borders or split-K
@@ -1829,7 +1853,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
             const long long nvec = (long long)p.M * Cout / 4;
             const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
             hipLaunchKernelGGL(dasv::conv3x3_splitk_reduce, dim3(blocks), dim3(256), 0, s, p.part, bias, mask, y, nvec, Cout,
-                               p.ksplit, relu, y_rec);
+                               p.ksplit, relu, y_rec, mask_packed);
         }
         return (int)hipGetLastError();
     }
@@ -1896,13 +1920,23 @@ int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint3
                           y_packed ? 1 : 0, x_range, y_range, 1, tile_pixels);
 }
 
-int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const float* bias,
-                                            float* y, uint32_t* y_range, uint8_t* idx, int B, int H, int W, int Cin, int Cout,
-                                            dasv_stream_t stream) {
+int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                            const float* bias, void* y, int y_packed, uint32_t* y_range, uint8_t* idx, int B, int H, int W,
+                                            int Cin, int Cout, dasv_stream_t stream) {
     if (idx == nullptr) return DASV_E_NULL;
     if (!dasv_conv3x3_pool_supported(3, B, H, W, Cin, Cout)) return DASV_E_SHAPE;
-    return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr, y, nullptr, 0, B, H, W, Cin, Cout, 1,
-                          stream, nullptr, 0, 0, x_range, y_range, 1, 0, idx);
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
+                          static_cast<float*>(y), nullptr, 0, B, H, W, Cin, Cout, 1, stream, nullptr, x_packed ? 1 : 0, y_packed ? 1 : 0,
+                          x_range, y_range, 1, 0, idx);
+}
+
+int dasv_conv3x3_masked_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask_packed,
+                                 float* y, uint32_t* y_range, float* colsum_partial, void* workspace, size_t workspace_bytes, int B, int H,
+                                 int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask_packed == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, static_cast<const float*>(mask_packed), colsum_partial, y,
+                          workspace, workspace_bytes, B, H, W, Cin, Cout, 0, stream, nullptr, 0, 0, x_range, y_range, 0, 0, nullptr, 1);
 }
 
 int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,

@@ -31,7 +31,8 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int WKC = 64;   // pixels per K chunk
 
 // timing experiments only (tools/wgrad_diag.py builds this file with -DDASV_WGRAD_DIAG=n; results are wrong then):
-// 1 = stage only the first two chunks, 2 = no MFMA section
+// 1 = stage only the first two chunks, 2 = no MFMA section, 3 = the x window parked as fetched (one 16-byte store per piece, no
+// conversion: what a PACKED x operand would cost the producers), 4 = x and g parked as fetched
 #ifndef DASV_WGRAD_DIAG
 #define DASV_WGRAD_DIAG 0
 #endif
@@ -129,8 +130,13 @@ __host__ __device__ constexpr size_t wgrad_buffer_bytes(int nx) {
 // (j / W + 1)(W + 2) + j % W + 1, a tap a shift by dy (W + 2) + dx — so, like the patches, no table and no carried coordinates:
 // a producer thread's window positions are constants of the launch.  For the 20- and 10-column maps of the default model the
 // raster form's producers (coordinate carries per fetched row, 114 / 97 window rows) were what the fp16 + e4m3 consumers waited for.
-template <bool SPLIT, int NX, int PATCH, bool X8 = false>
+// XP (with X8): x is a PACKED activation tensor (dasv_common.hpp, store_x8 — what the split8 forward chain writes): a 16-byte piece of a
+// pixel's 256-byte slab is already a piece of one of the three LDS planes, so the producers park the x window as fetched — no
+// conversion, one 16-byte LDS store per piece (the same global addresses: a slab of 64 packed channels is as long as 64 floats).
+// Measured with the pieces parked raw (tools/wgrad_diag.py, mode 3): 5.41 -> 4.34 ms over the seven layers of VGG4L/1024.
+template <bool SPLIT, int NX, int PATCH, bool X8 = false, bool XP = false>
 __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p) {
+    static_assert(!XP || X8, "a packed x operand is a split8 operand");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, H = p.H, Cin = p.Cin, Cout = p.Cout;
     const int HW = H * W;
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
     // X8: power-of-two scales from the range records (wave-uniform): max |v| 2^E in [128, 256)
     float sg = 1.f, sx = 1.f, sout = 1.f;
     if constexpr (X8) {
-        const int Eg = x8_exp_for(p.g_rec[0]), Ex = x8_exp_for(p.x_rec[0]);
+        const int Eg = x8_exp_for(p.g_rec[0]), Ex = XP ? (int)p.x_rec[1] : x8_exp_for(p.x_rec[0]);     // (a packed x was made with the exponent in its record)
         sg = x8_pow2(Eg);
         sx = x8_pow2(Ex);
         sout = x8_pow2(-Eg > -126 ? -Eg : -126) * x8_pow2(-Ex > -126 ? -Ex : -126);
@@ -333,6 +339,7 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
             for (int k = 0; k < 4; ++k) {
                 uint32_t h0_, l0_, h1_, l1_;
                 const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                if constexpr (DASV_WGRAD_DIAG == 4) { *reinterpret_cast<f32x4*>(Ghi + (srow + 16 * k) * 256 + scc * 16) = gr[k]; continue; }
                 if constexpr (X8) {
                     cvt4_x8(gr[k], sg, h0_, h1_, l0_, l1_);
                     const int o8 = w8_off(srow + 16 * k, scc >> 2) + (scc & 3) * 4;
@@ -349,6 +356,15 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
             for (int k = 0; k < NX; ++k) {
                 uint32_t h0_, l0_, h1_, l1_;
                 const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
+                if constexpr (DASV_WGRAD_DIAG == 3 || DASV_WGRAD_DIAG == 4) { *reinterpret_cast<f32x4*>(Xhi + (srow + 16 * k) * 256 + scc * 16) = xr[k]; continue; }
+                if constexpr (XP) {
+                    // piece scc of the slab: 0-7 the fp16 plane (8 channels each), 8-11 e4m3(x), 12-15 e4m3(xl 2^12) (16 channels each)
+                    const int row = srow + 16 * k;
+                    const int op = scc < 8 ? wg_off(row, scc >> 1) + (scc & 1) * 16
+                                           : (int)xplane + (scc < 12 ? 0 : (int)(xplane / 2)) + w8_off(row, scc & 3);
+                    *reinterpret_cast<f32x4*>(Xhi + op) = xr[k];
+                    continue;
+                }
                 if constexpr (X8) {
                     cvt4_x8(xr[k], sx, h0_, h1_, l0_, l1_);
                     const int o8 = w8_off(srow + 16 * k, scc >> 2) + (scc & 3) * 4;
@@ -614,6 +630,12 @@ int dasv_conv3x3_wgrad_x8_nhwc(const float* x, const uint32_t* x_range, const fl
     return wgrad_launch(3, x, x_range, g, g_range, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
 }
 
+int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                                void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (x_range == nullptr || g_range == nullptr) return DASV_E_NULL;
+    return wgrad_launch(4, static_cast<const float*>(x_packed), x_range, g, g_range, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
+}
+
 static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
                         void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (x == nullptr || g == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;
@@ -622,7 +644,7 @@ static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const
     // operands are addressed through 32-bit buffer offsets
     if ((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 >= 0xffffffffLL) return DASV_E_SHAPE;
     dasv::WgradParams p;
-    dasv::wgrad_plan(B, H, W, Cin, Cout, p, mode == 3);
+    dasv::wgrad_plan(B, H, W, Cin, Cout, p, mode >= 3);
     if (workspace_bytes < (size_t)p.S * Cout * 9 * Cin * sizeof(float)) return DASV_E_WORKSPACE;
     p.x = x; p.g = g; p.part = static_cast<float*>(workspace);
     p.x_rec = x_range; p.g_rec = g_range;
@@ -640,7 +662,14 @@ static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const
         hipLaunchKernelGGL((dasv::conv3x3_wgrad_kernel<SP, NXV, PT __VA_OPT__(,) __VA_ARGS__>), grid, block, lds, s, p); \
     } while (0)
     if (nx > 15) return DASV_E_SHAPE;   // maps wider than 80 columns
-    if (mode == 3) {
+    if (mode == 4) {       // split8, x packed
+        if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1, true, true);
+        else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2, true, true);
+        else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2, true, true);
+        else if (nx <= 8) DASV_LAUNCH_WGRAD(false, 8, 0, true, true);
+        else if (nx <= 10) DASV_LAUNCH_WGRAD(false, 10, 0, true, true);
+        else DASV_LAUNCH_WGRAD(false, 15, 0, true, true);
+    } else if (mode == 3) {
         if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1, true);
         else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2, true);
         else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2, true);

@@ -354,13 +354,25 @@ int dasv_conv3x3_bias_relu_pool_x8_nhwc(const void* x, int x_packed, const uint3
 int dasv_conv3x3_bias_relu_pool_f16_nhwc(const void* x, int x_f16, const uint32_t* x_range, const void* w_f16, const float* bias,
                                          void* y, int y_f16, uint32_t* y_range, int B, int H, int W, int Cin, int Cout,
                                          int tile_pixels, dasv_stream_t stream);
-/* The TRAINING form (train.py:215-220 through the same lines of CNNs.py): fp32 x, fp32 pooled y, and idx [B, ceil(H/2), ceil(W/2), Cout]
+/* The TRAINING form (train.py:215-220 through the same lines of CNNs.py): x and the pooled y fp32 or PACKED (x_packed / y_packed as in
+ * dasv_conv3x3_bias_relu_pool_x8_nhwc), and idx [B, ceil(H/2), ceil(W/2), Cout]
  * bytes {arg-max position 0-3 (row-major in the window, the first maximum wins — ATen's tie-breaking) | 4 if the maximum is > 0}, the
  * bytes dasv_maxpool2x2_ceil_idx_nhwc writes: dasv_maxpool2x2_ceil_bwd_idx_nhwc(relu_mask = 1) turns the pooled gradient into the
  * gradient at convX2's pre-activation from them alone, so the full-resolution activation map is neither written nor kept. */
-int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const float* bias,
-                                            float* y, uint32_t* y_range, uint8_t* idx, int B, int H, int W, int Cin, int Cout,
-                                            dasv_stream_t stream);
+int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                            const float* bias, void* y, int y_packed, uint32_t* y_range, uint8_t* idx, int B, int H, int W,
+                                            int Cin, int Cout, dasv_stream_t stream);
+/* The training chain on PACKED activations (every activation of the forward pass in the split8 operand form, nothing in fp32 except
+ * the last pooled map): the backward's two consumers of an activation tensor read the packed form directly —
+ *   dasv_conv3x3_masked_x8p_nhwc  the data gradient with the ReLU mask taken from a packed tensor (the sign of its fp16 plane);
+ *                                 workspace as dasv_conv3x3_bias_relu_nhwc_ws (small batches; not with colsum_partial)
+ *   dasv_conv3x3_wgrad_x8p_nhwc   the weight gradient with x packed (its pieces are parked in LDS as fetched: no conversion work
+ *                                 in the producer waves; x_range[1] = the exponent the tensor was packed with). */
+int dasv_conv3x3_masked_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask_packed,
+                                 float* y, uint32_t* y_range, float* colsum_partial, void* workspace, size_t workspace_bytes, int B, int H,
+                                 int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+                                void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
 int dasv_maxpool2x2_ceil_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, int B, int H, int W,

@@ -7,6 +7,14 @@ import torch
 import torch.nn.functional as F
 
 
+def packed_sign(t):
+    """(v > 0) of a PACKED activation tensor [B,C,H,W] (conv.conv3x3_x8: every 256-byte slab of 64 channels starts with the 64 fp16
+    values c = v * 2^E), as a bool tensor of the same shape."""
+    B, C, H, W = t.shape
+    raw = t.detach().permute(0, 2, 3, 1).contiguous().view(torch.uint8).view(B, H, W, C // 64, 256)[..., :128].contiguous()
+    return (raw.view(torch.float16).reshape(B, H, W, C) > 0).permute(0, 3, 1, 2)
+
+
 class DecisionCapture:
     """with DecisionCapture(monkeypatch, front_end) as cap: y = front_end(x) ...; cap.decisions() -> dict for the oracle (CPU).
     One forward pass per capture (call `reset()` between passes)."""
@@ -32,12 +40,12 @@ class DecisionCapture:
 
         def conv(*a, **k):
             y = oc(*a, **k)
-            self.events.append(("conv", y.detach()))
+            self.events.append(("conv", packed_sign(y) if k.get("y_packed") else y.detach()))
             return y
 
         def c1(*a, **k):
             y = o1(*a, **k)
-            self.events.append(("conv", y.detach()))
+            self.events.append(("conv", packed_sign(y) if k.get("pack") else y.detach()))
             return y
 
         def pool(h, *a, **k):

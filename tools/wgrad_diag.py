@@ -6,7 +6,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIAG = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "doubleattentionspeakerverification_amd", "csrc", "conv3x3_wgrad.hip")
-NAMES = {0: "full", 1: "no re-staging", 2: "no MFMA"}
+NAMES = {0: "full", 1: "no re-staging", 2: "no MFMA", 3: "x parked raw", 4: "x and g parked raw"}
 
 
 def so(n):
