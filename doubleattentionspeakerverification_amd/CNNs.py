@@ -93,6 +93,9 @@ class _VGG(nn.Module):
         # inference chain plus the pools' arg-max bytes; only the last pooled map is fp32) — the next layer's staging, the weight
         # gradient's producers and the data gradient's mask read all take the packed form as it is (_forward_map_packed_train)
         self.packed_training = True
+        # ... with the first block as one autograd node whose backward folds conv11's weight / bias gradient into conv12's data-gradient
+        # launch (conv.first_block_train): the gradient at conv11's output is never written
+        self.fuse_first_backward = True
         self._packed = {}
 
     def _mode(self):
@@ -240,8 +243,15 @@ class _VGG(nn.Module):
             _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                        "dasv_range_absmax_f32")
         rh = next(r)
-        h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, pack=True, x_rec=rx)
-        for blk in range(1, self.n_blocks + 1):
+        first = 1
+        if self.fuse_first_backward and self.conv11.bias is not None:
+            ry = next(r)
+            h = _hipconv.first_block_train(x, self.conv11.weight, self.conv11.bias, self.conv12.weight, self.conv12.bias,
+                                           self._pk("conv12", dev), rx, rh, ry, y_packed=self.n_blocks > 1)
+            rh, first = ry, 2
+        else:
+            h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, pack=True, x_rec=rx)
+        for blk in range(first, self.n_blocks + 1):
             n1, n2 = "conv%d1" % blk, "conv%d2" % blk
             c1, c2 = getattr(self, n1), getattr(self, n2)
             l1 = {}

@@ -491,6 +491,77 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         return _conv_backward(ctx, x, weight, g, _rec_of(gy), C) + (None,) * 8
 
 
+class _FirstBlockFn(torch.autograd.Function):
+    """The first VGG block of the packed training chain as ONE autograd node — `pool(relu(conv12(relu(conv11(mel)))))`, CNNs.py:38-40 /
+    72-74: forward = the one-channel kernel (packed output) + the conv + ReLU + pool launch with arg-max bytes; backward = the pool's
+    scatter, conv12's weight gradient from the packed activations, and conv12's data-gradient launch with conv11's WHOLE backward in its
+    write-out pass (dasv_conv3x3_masked_c1_x8p_nhwc): the gradient at conv11's output — the largest tensor of the step — is never
+    written."""
+
+    @staticmethod
+    def forward(ctx, mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, y_packed, fresh):
+        lib = _lib.load()
+        h = conv3x3_c1_bias_relu(mel, w11, b11, pack=True, x_rec=x_rec, y_rec=h_rec)
+        B, C1, H, W = h.shape
+        C2 = w12.shape[0]
+        hi, lo = packed12.get(w12, "split8", b12, fresh=fresh)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((B, C2, Ho, Wo), dtype=torch.float32, device=h.device, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, C2), dtype=torch.uint8, device=h.device)
+        with torch.cuda.device(h.device):
+            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(h.data_ptr(), 1, h_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                             None if b12 is None else b12.data_ptr(), y.data_ptr(), int(y_packed),
+                                                             y_rec.data_ptr(), idx.data_ptr(), B, H, W, C1, C2,
+                                                             torch.cuda.current_stream(h.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
+        ctx.save_for_backward(mel.contiguous(), h, w12, idx)
+        ctx.h_rec, ctx.bias = h_rec, (b11 is not None, b12 is not None)
+        ctx.w11_shape = w11.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mel, h, w12, idx = ctx.saved_tensors
+        lib = _lib.load()
+        B, C1, H, W = h.shape
+        C2 = w12.shape[0]
+        dev = gy.device
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g = torch.empty((B, C2, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        g_rec = _rec_of(gy)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C2) if ctx.bias[1] else 0
+            part = torch.empty((rows, C2), dtype=torch.float32, device=dev) if rows > 0 else None
+            _lib.check(lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), g.data_ptr(), None if part is None else part.data_ptr(),
+                                                             1, B, H, W, C2, st), "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
+            if g_rec is None:
+                g_rec = range_of(g)
+            gw12 = conv3x3_wgrad(h, g, "split8", x_rec=ctx.h_rec, g_rec=g_rec, x_packed=True) if ctx.needs_input_grad[3] else None
+            gb12 = part.sum(dim=0) if part is not None and ctx.needs_input_grad[4] else None
+            gw11 = gb11 = None
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                hi, lo = _pack_dgrad_x8(w12.detach())
+                prow = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0)
+                cpart = torch.empty((prow, C1, 10), dtype=torch.float32, device=dev)
+                _lib.check(lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), h.data_ptr(), 1,
+                                                               mel.data_ptr(), cpart.data_ptr(), B, H, W, C2, C1, st),
+                           "dasv_conv3x3_masked_c1_x8p_nhwc")
+                gw11 = torch.empty(ctx.w11_shape, dtype=torch.float32, device=dev)
+                gb11 = torch.empty(C1, dtype=torch.float32, device=dev) if ctx.bias[0] else None
+                _lib.check(lib.dasv_conv3x3_c1_bwd_reduce_parts(cpart.data_ptr(), prow, gw11.data_ptr(), None if gb11 is None else gb11.data_ptr(),
+                                                                C1, st), "dasv_conv3x3_c1_bwd_reduce_parts")
+        return None, gw11, gb11, gw12, gb12, None, None, None, None, None, None
+
+
+def first_block_train(mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, y_packed=True):
+    """Differentiable (w.r.t. the four parameters) first block on packed activations: mel [B,H,W] fp32 -> the pooled map
+    [B, C, ceil(H/2), ceil(W/2)] (packed when y_packed); x_rec = the record of mel (filled), h_rec / y_rec = fresh records.  Channel counts:
+    conv11's output a power of two in [128, 1024], conv12 exact (conv.exact), the shape pool_fusable."""
+    fresh = torch.is_grad_enabled() and w12.requires_grad
+    return _FirstBlockFn.apply(mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, y_packed, fresh)
+
+
 def conv3x3_bias_relu_pool(x, weight, bias, packed=None, mask_input_grad=False, link_out=None, x_rec=None, y_rec=None, x_packed=False,
                            y_packed=False):
     """Differentiable `max_pool2d(relu(conv2d(x, weight, bias, padding 1)), 2, stride=2, ceil_mode=True)` in the split8 mode for shapes

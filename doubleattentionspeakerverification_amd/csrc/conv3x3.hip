@@ -273,6 +273,13 @@ struct ConvParams {
     // covers `pool_units` whole ROW PAIRS (units; the last unit of an image with an odd H is a single row) instead of TBM raster
     // pixels, so that every 2x2 window lies inside one tile: pool_units * 2 * W <= TBM, pool_U = ceil(H/2) units per image.
     int pool, pool_units, pool_U;
+    // data gradient of the SECOND layer with the FIRST layer's backward in its write-out pass (split8, pipelined launches): the first
+    // layer has one input channel (CNNs.py:38 / 72, conv11), so its weight gradient is gw1[c][tap] = sum_pix g1[pix][c] mel[pix + tap]
+    // with g1 = this launch's masked output — 9 FMAs per element while the tile is in hand — and its bias gradient the column sum.
+    // c1_part: [mtiles][Cout][10] per-tile sums {9 taps, bias} (dasv_conv3x3_c1_bwd_reduce_parts adds them up); y may then be null:
+    // the gradient at the first layer's output (786 MB for a [64,300,80] batch) is needed by nobody else
+    const float* c1_mel;   // [B,H,W]
+    float* c1_part;
     uint8_t* pool_idx;     // (training, fp32 y) [B, ceil(H/2), ceil(W/2), Cout] bytes {arg-max position 0-3 | 4 if the maximum is > 0}: what
                            // the pool's backward needs (frontend_misc.hip, maxpool2x2_bwd_nhwc_kernel) — the full-resolution map is
                            // then needed by nobody
@@ -1474,6 +1481,10 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             // the mask rows of the first passes are requested before the image is read
             static_assert(NT == 512, "16 pixel rows per pass");
             f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+            const bool c1f = X8 && p.c1_part != nullptr;
+            f32x4 wacc[9];                      // (c1f) the first layer's weight-gradient sums of this thread's four channels
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             constexpr int KB = 4;               // passes whose mask rows are in flight together
 #pragma unroll
             for (int k0 = 0; k0 < TBM / 16; k0 += KB) {
@@ -1507,12 +1518,48 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = mk[k][r] > 0.f ? v[r] : 0.f;
                         if (p.mask != nullptr) note4(v);
-                        *reinterpret_cast<f32x4*>(p.y + (size_t)mm[k] * p.Cout + n0 + col * 4) = v;
+                        if (p.y != nullptr) *reinterpret_cast<f32x4*>(p.y + (size_t)mm[k] * p.Cout + n0 + col * 4) = v;
                         csum += v;
+                        if constexpr (X8) {
+                            if (c1f) {
+                                int h_, w_;
+                                if constexpr (GEOM == 1) { h_ = gh0 + (pix >> 4); w_ = gw0 + (pix & 15); }
+                                else { w_ = mm[k] % W; h_ = (mm[k] / W) % H; }
+                                const float* mp = p.c1_mel + mm[k];
+#pragma unroll
+                                for (int t = 0; t < 9; ++t) {
+                                    const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                                    const float in = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? mp[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                                    wacc[t] += v * in;
+                                }
+                            }
+                        }
                     }
                 }
             }
             if (p.mask != nullptr && p.y_rec != nullptr) range_note(p.y_rec, amax_u, rec_seen);
+            if constexpr (X8) {
+                if (c1f) {                       // fixed order: a thread's pixel rows (above), then the 16 pixel-row groups
+                    float* red = reinterpret_cast<float*>(smem);       // [16][128 channels][10]
+                    __syncthreads();             // every thread is done with the image
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float* dst = red + ((tid >> 5) * 128 + col * 4 + c) * 10;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) dst[t] = wacc[t][c];
+                        dst[9] = csum[c];
+                    }
+                    __syncthreads();
+                    for (int i = tid; i < 1280; i += NT) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) t += red[g * 1280 + i];
+                        p.c1_part[((size_t)mt * p.Cout + n0) * 10 + i] = t;
+                    }
+                    DASV_STAMP(63);
+                    return;
+                }
+            }
             if (p.colsum != nullptr) {           // fixed order: a thread's pixel rows (above), then the 16 pixel-row groups
                 float* red = reinterpret_cast<float*>(smem);
                 __syncthreads();                 // every thread is done with the image
@@ -1710,8 +1757,11 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           const void* w_lo, const float* bias, const float* mask, float* colsum, float* y, void* workspace,
                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream,
                           const int* row_span = nullptr, int x_packed = 0, int y_packed = 0, const uint32_t* x_rec = nullptr,
-                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr, int mask_packed = 0) {
-    if ((x == nullptr && mel == nullptr) || w_hi == nullptr || y == nullptr || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
+                          uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr, int mask_packed = 0,
+                          const float* c1_mel = nullptr, float* c1_part = nullptr) {
+    if ((x == nullptr && mel == nullptr) || w_hi == nullptr || (y == nullptr && c1_part == nullptr) || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
+    if (c1_part != nullptr && (c1_mel == nullptr || mode != 3 || mask == nullptr || colsum != nullptr || workspace != nullptr || row_span != nullptr ||
+                               W > 80 || pool)) return DASV_E_SHAPE;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return DASV_E_SHAPE;
@@ -1727,6 +1777,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     p.x_packed = x_packed; p.y_packed = y_packed;
     p.x_rec = x_rec; p.y_rec = y_rec;
     p.mask_packed = mask_packed;
+    p.c1_mel = c1_mel; p.c1_part = c1_part;
     if (y_packed && (mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
     if ((x_packed || y_packed) && mel != nullptr) return DASV_E_SHAPE;
     if ((x_packed == 1 || y_packed == 1) && mode != 3) return DASV_E_SHAPE;        // packed split8 planes
@@ -1760,6 +1811,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         const bool dbuf = (two || mel == nullptr) && lds1 + 32768 + 128 <= 160 * 1024;
         // (a packed mask is read by the pipelined launches' write-out pass or by the split-K reduction)
         if (mask_packed && S == 1 && !dbuf) return DASV_E_SHAPE;
+        if (c1_part != nullptr && !dbuf) return DASV_E_SHAPE;
         // patch tiles (GEOM = 1): maps whose width is a multiple of 16 and whose raster window would be larger than the 18 x 18
         // patch window (80 / 64 / 48 columns; the 80-column first block in this model) — pipelined split8 launches (forward and
         // masked data gradient) without ragged borders or split-K
@@ -2007,6 +2059,14 @@ int dasv_conv3x3_masked_x8_nhwc(const float* x, const uint32_t* x_range, const v
     if (W > 80) return DASV_E_SHAPE;
     return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, mask, colsum_partial, y, nullptr, 0, B, H, W,
                           Cin, Cout, 0, stream, nullptr, 0, 0, x_range, y_range);
+}
+
+int dasv_conv3x3_masked_c1_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask, int mask_packed,
+                                    const float* mel, float* c1_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask == nullptr || mel == nullptr || c1_partial == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, x, nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, static_cast<const float*>(mask), nullptr, nullptr, nullptr, 0,
+                          B, H, W, Cin, Cout, 0, stream, nullptr, 0, 0, x_range, nullptr, 0, 0, nullptr, mask_packed ? 1 : 0, mel, c1_partial);
 }
 
 int dasv_conv3x3_masked_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,

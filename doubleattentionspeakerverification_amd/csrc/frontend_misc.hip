@@ -729,6 +729,14 @@ int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float*
     return c1_bwd_launch(x, y, gy, gw, gb, workspace, workspace_bytes, 1, rows, W, Cout, stream, row_span);
 }
 
+int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, float* gb, int Cout, dasv_stream_t stream) {
+    if (partial == nullptr || gw == nullptr) return DASV_E_NULL;
+    if (rows <= 0 || Cout <= 0) return DASV_E_SHAPE;
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, gw,
+                       gb, rows, Cout);
+    return (int)hipGetLastError();
+}
+
 static int c1_bwd_launch(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
                          size_t workspace_bytes, int B, int H, int W, int Cout, dasv_stream_t stream, const int* row_span) {
     if (x == nullptr || gy == nullptr || gw == nullptr || workspace == nullptr) return DASV_E_NULL;      // y may be NULL: gy pre-masked

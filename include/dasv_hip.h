@@ -371,6 +371,15 @@ int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const void* x, int x_packed, const u
 int dasv_conv3x3_masked_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask_packed,
                                  float* y, uint32_t* y_range, float* colsum_partial, void* workspace, size_t workspace_bytes, int B, int H,
                                  int W, int Cin, int Cout, dasv_stream_t stream);
+/* The data gradient of the SECOND layer with the FIRST layer's whole backward in its write-out pass (train.py:220 through CNNs.py:38-39 /
+ * 72-73): conv11 has one input channel, so its weight gradient gw[c][tap] = sum_pix g1[pix][c] * mel[pix + tap] (g1 = this launch's
+ * masked output) costs 9 FMAs per element while the tile is in hand, and its bias gradient is the column sum.  The gradient at
+ * conv11's output (786 MB for a [64,300,80] batch) is then written and read by nobody.  c1_partial: [dasv_conv3x3_colsum_rows(3, B,
+ * H, W, 0)][Cout][10] floats {nine taps, bias} per pixel tile; dasv_conv3x3_c1_bwd_reduce_parts sums the rows in a fixed order into
+ * gw [Cout][1][3][3] and gb [Cout] (gb may be NULL).  mask: conv11's ReLU output, fp32 or packed (mask_packed). */
+int dasv_conv3x3_masked_c1_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask, int mask_packed,
+                                    const float* mel, float* c1_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, float* gb, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,

@@ -56,6 +56,17 @@ class DecisionCapture:
         self.mp.setattr(C, "conv3x3_c1_bias_relu_autograd", c1)
         self.mp.setattr(C, "maxpool2x2_ceil_autograd", pool)
         self.mp.setattr(C, "conv3x3_bias_relu_pool", convpool)
+        ofb = C.first_block_train
+
+        def first_block(*a, **k):
+            # conv11 + conv12 + pool as one autograd node: conv11's packed output and the pool's bytes are saved on the node
+            y = ofb(*a, **k)
+            _, h, _, idx = y.grad_fn.saved_tensors
+            self.events.append(("conv", packed_sign(h)))
+            self.events.append(("convpool", (idx.detach(), h.shape[2], h.shape[3])))
+            return y
+
+        self.mp.setattr(C, "first_block_train", first_block)
         return self
 
     def __exit__(self, *exc):

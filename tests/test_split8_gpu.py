@@ -294,19 +294,23 @@ def test_narrow_kernel_size_training_gradients_vs_float64_under_the_same_decisio
         assert err < 2e-4, (k, err)          # of the tensor's scale; split8 products are ~1e-5 per layer
 
 
-def test_packed_training_chain_gradients_vs_float64_under_the_same_decisions(monkeypatch):
+@pytest.mark.parametrize("first_block_node", [True, False])
+def test_packed_training_chain_gradients_vs_float64_under_the_same_decisions(first_block_node, monkeypatch):
     """The training step's front-end on PACKED activations (CNNs._forward_map_packed_train: what a dense VGG4L/1024 batch runs —
     conv11 -> packed -> conv12 + pool + arg-max bytes -> packed -> ... ; weight gradients from packed x operands
     (dasv_conv3x3_wgrad_x8p_nhwc), data gradients with the ReLU mask read from the packed tensor's fp16 plane
     (dasv_conv3x3_masked_x8p_nhwc), no fp32 activation tensor except the last pooled map): every parameter's gradient element by
     element against the float64 gradients of CNNs.py:68-91 under the decisions this forward took (ReLU signs from the packed
     tensors' fp16 planes, arg-maxes from the pools' bytes), flips against the float64 forward's own decisions counted.  Then the same
-    batch through the per-layer fp32 wiring: forward values within 2e-5."""
+    batch through the per-layer fp32 wiring: forward values within 2e-5.
+    first_block_node: the first block as ONE autograd node whose backward forms conv11's weight / bias gradient inside conv12's
+    data-gradient launch (conv.first_block_train, dasv_conv3x3_masked_c1_x8p_nhwc; the shipped wiring) — or conv11 as its own node."""
     from doubleattentionspeakerverification_amd.CNNs import VGG4L
     from doubleattentionspeakerverification_amd import conv as C
     from _decisions import DecisionCapture
     torch.manual_seed(7)
     net = VGG4L(1024).to(DEV).train()
+    net.fuse_first_backward = first_block_node
     B, T = 128, 40
     assert net._packed_training_ok(80, B, T)
     x = torch.from_numpy(rnd(61, B, T, 80))
