@@ -220,6 +220,8 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
         raise RuntimeError("packed activation tensors belong to the split8 mode on dense batches")
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        if x_packed and mask is not None and not mask_packed:
+            raise RuntimeError("a packed gradient operand belongs to the packed training chain (packed mask)")
         if mode == "split8" and (x_packed or y_packed) and mask is None:
             rc = lib.dasv_conv3x3_bias_relu_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
                                                     None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
@@ -229,7 +231,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
             nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout) if part is None else 0      # (column sums: one pass)
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-            rc = lib.dasv_conv3x3_masked_x8p_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
+            rc = lib.dasv_conv3x3_masked_x8p_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), y.data_ptr(),
                                                   None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
                                                   None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, stream)
             if part is not None and rc == 0:
@@ -273,7 +275,7 @@ def supported_wgrad(cin, cout, width=1, pixels=0):
     return cin % 64 == 0 and cout % 64 == 0 and width <= 80 and pixels * max(cin, cout) * 4 < 0xffffffff
 
 
-def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_packed=False):
+def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_packed=False, g_packed=False):
     """Weight gradient [Cout,Cin,3,3] of conv3x3 (stride 1, pad 1) from x [B,Cin,H,W] and g [B,Cout,H,W]
     (both channels_last fp32) on the hand-written MFMA kernel (csrc/conv3x3_wgrad.hip).
     mode "split8": fp16 products + block-scaled e4m3 cross terms; x_rec / g_rec are the operands' range records (an upper bound
@@ -283,9 +285,12 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
     the previous utterance's last row (taps ky = 0) and g of a last row with x of the next first row (ky = 2); exactly those products
     are computed a second time from 2-row images {last row | first row} and subtracted.
     x_packed (split8, dense): x is a PACKED activation tensor and x_rec the record its producer filled — the kernel's producer waves
-    then copy instead of converting (dasv_conv3x3_wgrad_x8p_nhwc)."""
+    then copy instead of converting (dasv_conv3x3_wgrad_x8p_nhwc); g_packed (with x_packed): g is packed too (the pool's backward
+    wrote it that way), g_rec its record."""
     if x_packed and (mode != "split8" or x_rec is None or borders is not None):
         raise RuntimeError("a packed x operand: split8 mode, dense batch, with the record its producer filled")
+    if g_packed and not (x_packed and g_rec is not None):
+        raise RuntimeError("a packed g operand: with a packed x, and the record its producer filled")
     if borders is not None and borders.numel() > 0:
         if x.shape[0] != 1:
             raise RuntimeError("a ragged batch is one stacked image")
@@ -305,6 +310,8 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
     if not g.is_contiguous(memory_format=torch.channels_last):
+        if g_packed:
+            raise RuntimeError("a packed tensor must keep its channels_last layout")
         g = g.contiguous(memory_format=torch.channels_last)
     gw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
     nbytes = lib.dasv_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
@@ -313,9 +320,13 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
         x_rec = range_of(x) if x_rec is None else x_rec
         g_rec = range_of(g) if g_rec is None else g_rec
         with torch.cuda.device(x.device):
-            fn = lib.dasv_conv3x3_wgrad_x8p_nhwc if x_packed else lib.dasv_conv3x3_wgrad_x8_nhwc
-            rc = fn(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), g_rec.data_ptr(), gw.data_ptr(), ws.data_ptr(),
-                    nbytes, B, H, W, cin, cout, torch.cuda.current_stream(x.device).cuda_stream)
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            if x_packed:
+                rc = lib.dasv_conv3x3_wgrad_x8p_nhwc(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), int(g_packed), g_rec.data_ptr(), gw.data_ptr(),
+                                                     ws.data_ptr(), nbytes, B, H, W, cin, cout, st)
+            else:
+                rc = lib.dasv_conv3x3_wgrad_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), g.data_ptr(), g_rec.data_ptr(), gw.data_ptr(), ws.data_ptr(),
+                                                    nbytes, B, H, W, cin, cout, st)
         _lib.check(rc, "dasv_conv3x3_wgrad_x8_nhwc")
         return gw
     with torch.cuda.device(x.device):
@@ -360,9 +371,10 @@ class _ConvReLUFn(torch.autograd.Function):
         return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1]) + (None,) * 13
 
 
-def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
+def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p, g_packed=False):
     """(gx, gw, gb) of a conv3x3 + bias layer from g = the gradient at its pre-activation [B, cout_p, H, W] (channels_last fp32; g_rec_in
-    its range record or None) — shared by the layer's own autograd node and by the conv + ReLU + max-pool node."""
+    its range record or None) — shared by the layer's own autograd node and by the conv + ReLU + max-pool node.
+    g_packed (packed training chain): g is a packed tensor (the pool's backward wrote it so), g_rec_in its record."""
     cout, cin = weight.shape[0], weight.shape[1]
     cin_x = x.shape[1]        # (with cout_p: the padded layer that ran forward)
     padded = (cin_x, cout_p) != (cin, cout)
@@ -398,7 +410,7 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
             # backward is applied in this kernel's epilogue
             gx = _launch(g, hi, lo, None, cin_x, dmode, relu=0, mask=x if ctx.mask_input_grad else None,
                          colsum=ctx.link_out if ctx.mask_input_grad else None, x_rec=g_rec, y_rec=gx_rec, span=ctx.span,
-                         mask_packed=ctx.x_packed and ctx.mask_input_grad)
+                         mask_packed=ctx.x_packed and ctx.mask_input_grad, x_packed=g_packed)
             if gx_rec is not None:
                 _attach_rec(gx, gx_rec)
         else:
@@ -414,7 +426,7 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
         # (the record of the gradient BEFORE this layer's ReLU mask bounds the masked one)
         gw = conv3x3_wgrad(x, g, wmode, x_rec=ctx.x_rec if wmode == "split8" else None,
                            g_rec=g_rec_in if wmode == "split8" else None, borders=ctx.borders if ctx.span is not None else None,
-                           x_packed=ctx.x_packed)
+                           x_packed=ctx.x_packed, g_packed=g_packed)
         if padded:
             gw = gw[:cout, :cin].contiguous()
         want_w = False
@@ -422,6 +434,8 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
             # the kernel that produced this (pre-masked) gradient may have left its per-channel sums behind
             gb = ctx.link_in.pop("gb", None) if (ctx.grad_premasked and ctx.link_in is not None) else None
             if gb is None:
+                if g_packed:
+                    raise RuntimeError("packed training chain: the bias gradient comes from the pool's backward")
                 gb = g.sum(dim=(0, 2, 3))
             gb = gb[:cout] if padded else gb
             want_b = False
@@ -438,6 +452,33 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p):
         gw = (gw2[:cout, :cin].contiguous() if padded else gw2) if want_w else gw
         gb = (gb2[:cout] if padded else gb2) if want_b else gb
     return gx, gw, gb
+
+
+def _pool_scatter(idx, gy, B, H, W, C, want_sum, packed):
+    """The pool's backward from the forward's arg-max bytes (which carry the ReLU's mask too): (g [B,C,H,W], its range record or None,
+    per-workgroup column sums or None).  packed: g is written as a PACKED tensor scaled by the exponent of gy's maximum (the
+    scattered tensor's own maximum) — its consumers, the layer's data- and weight-gradient launches, then copy its pieces."""
+    lib = _lib.load()
+    dev = gy.device
+    g = torch.empty((B, C, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    g_rec = _rec_of(gy)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if want_sum else 0
+        part = torch.empty((rows, C), dtype=torch.float32, device=dev) if rows > 0 else None
+        if packed:
+            if g_rec is None:
+                g_rec = range_of(gy)           # (a gradient no kernel of this library produced: one pass over the POOLED tensor)
+            rec = new_ranges(dev)[0]
+            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc(idx.data_ptr(), gy.data_ptr(), g_rec.data_ptr(), g.data_ptr(), rec.data_ptr(),
+                                                          None if part is None else part.data_ptr(), 1, B, H, W, C, st)
+            g_rec = rec
+        else:
+            # (the scattered gradient's range record is its source's: max |g| <= max |gy|)
+            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), g.data_ptr(), None if part is None else part.data_ptr(),
+                                                       1, B, H, W, C, st)
+    _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
+    return g, g_rec, part
 
 
 class _ConvReLUPoolFn(torch.autograd.Function):
@@ -478,17 +519,10 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         B, _, H, W = x.shape
         C = weight.shape[0]
         gy = gy.contiguous(memory_format=torch.channels_last)
-        g = torch.empty((B, C, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
-        with torch.cuda.device(gy.device):
-            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C) if ctx.has_bias else 0
-            part = torch.empty((rows, C), dtype=torch.float32, device=gy.device) if rows > 0 else None
-            rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), g.data_ptr(), None if part is None else part.data_ptr(),
-                                                       1, B, H, W, C, torch.cuda.current_stream(gy.device).cuda_stream)
-        _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
+        g, g_rec, part = _pool_scatter(idx, gy, B, H, W, C, ctx.has_bias, packed=ctx.x_packed)
         if part is not None:
             ctx.link_in["gb"] = part.sum(dim=0)
-        # (the scattered gradient's range record is its source's: max |g| <= max |gy|)
-        return _conv_backward(ctx, x, weight, g, _rec_of(gy), C) + (None,) * 8
+        return _conv_backward(ctx, x, weight, g, g_rec, C, g_packed=ctx.x_packed) + (None,) * 8
 
 
 class _FirstBlockFn(torch.autograd.Function):
@@ -527,24 +561,17 @@ class _FirstBlockFn(torch.autograd.Function):
         C2 = w12.shape[0]
         dev = gy.device
         gy = gy.contiguous(memory_format=torch.channels_last)
-        g = torch.empty((B, C2, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        g_rec = _rec_of(gy)
+        g, g_rec, part = _pool_scatter(idx, gy, B, H, W, C2, ctx.bias[1], packed=True)
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            rows = lib.dasv_maxpool2x2_bwd_colsum_rows(B, H, W, C2) if ctx.bias[1] else 0
-            part = torch.empty((rows, C2), dtype=torch.float32, device=dev) if rows > 0 else None
-            _lib.check(lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), g.data_ptr(), None if part is None else part.data_ptr(),
-                                                             1, B, H, W, C2, st), "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
-            if g_rec is None:
-                g_rec = range_of(g)
-            gw12 = conv3x3_wgrad(h, g, "split8", x_rec=ctx.h_rec, g_rec=g_rec, x_packed=True) if ctx.needs_input_grad[3] else None
+            gw12 = conv3x3_wgrad(h, g, "split8", x_rec=ctx.h_rec, g_rec=g_rec, x_packed=True, g_packed=True) if ctx.needs_input_grad[3] else None
             gb12 = part.sum(dim=0) if part is not None and ctx.needs_input_grad[4] else None
             gw11 = gb11 = None
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 hi, lo = _pack_dgrad_x8(w12.detach())
                 prow = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0)
                 cpart = torch.empty((prow, C1, 10), dtype=torch.float32, device=dev)
-                _lib.check(lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), h.data_ptr(), 1,
+                _lib.check(lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), h.data_ptr(), 1,
                                                                mel.data_ptr(), cpart.data_ptr(), B, H, W, C2, C1, st),
                            "dasv_conv3x3_masked_c1_x8p_nhwc")
                 gw11 = torch.empty(ctx.w11_shape, dtype=torch.float32, device=dev)

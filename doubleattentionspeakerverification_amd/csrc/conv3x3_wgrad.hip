@@ -134,9 +134,11 @@ __host__ __device__ constexpr size_t wgrad_buffer_bytes(int nx) {
 // pixel's 256-byte slab is already a piece of one of the three LDS planes, so the producers park the x window as fetched — no
 // conversion, one 16-byte LDS store per piece (the same global addresses: a slab of 64 packed channels is as long as 64 floats).
 // Measured with the pieces parked raw (tools/wgrad_diag.py, mode 3): 5.41 -> 4.34 ms over the seven layers of VGG4L/1024.
-template <bool SPLIT, int NX, int PATCH, bool X8 = false, bool XP = false>
+// GP (with XP): g is a packed tensor too (the pool's backward writes it that way, dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc).
+template <bool SPLIT, int NX, int PATCH, bool X8 = false, bool XP = false, bool GP = false>
 __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p) {
     static_assert(!XP || X8, "a packed x operand is a split8 operand");
+    static_assert(!GP || XP, "packed g: the packed training chain (x packed as well)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, H = p.H, Cin = p.Cin, Cout = p.Cout;
     const int HW = H * W;
@@ -165,7 +167,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
     // X8: power-of-two scales from the range records (wave-uniform): max |v| 2^E in [128, 256)
     float sg = 1.f, sx = 1.f, sout = 1.f;
     if constexpr (X8) {
-        const int Eg = x8_exp_for(p.g_rec[0]), Ex = XP ? (int)p.x_rec[1] : x8_exp_for(p.x_rec[0]);     // (a packed x was made with the exponent in its record)
+        // (a packed operand was made with the exponent in its record)
+        const int Eg = GP ? (int)p.g_rec[1] : x8_exp_for(p.g_rec[0]), Ex = XP ? (int)p.x_rec[1] : x8_exp_for(p.x_rec[0]);
         sg = x8_pow2(Eg);
         sx = x8_pow2(Ex);
         sout = x8_pow2(-Eg > -126 ? -Eg : -126) * x8_pow2(-Ex > -126 ? -Ex : -126);
@@ -340,6 +343,13 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad_kernel(const WgradParams p)
                 uint32_t h0_, l0_, h1_, l1_;
                 const int o = wg_off(srow + 16 * k, scc >> 2) + (scc & 3) * 8;
                 if constexpr (DASV_WGRAD_DIAG == 4) { *reinterpret_cast<f32x4*>(Ghi + (srow + 16 * k) * 256 + scc * 16) = gr[k]; continue; }
+                if constexpr (GP) {           // piece scc of the pixel's slab: fp16 plane | e4m3(g) | e4m3(gl 2^12)  (see XP below)
+                    const int row = srow + 16 * k;
+                    const int op = scc < 8 ? wg_off(row, scc >> 1) + (scc & 1) * 16
+                                           : WKC * 128 + (scc < 12 ? 0 : WKC * 64) + w8_off(row, scc & 3);
+                    *reinterpret_cast<f32x4*>(Ghi + op) = gr[k];
+                    continue;
+                }
                 if constexpr (X8) {
                     cvt4_x8(gr[k], sg, h0_, h1_, l0_, l1_);
                     const int o8 = w8_off(srow + 16 * k, scc >> 2) + (scc & 3) * 4;
@@ -630,10 +640,11 @@ int dasv_conv3x3_wgrad_x8_nhwc(const float* x, const uint32_t* x_range, const fl
     return wgrad_launch(3, x, x_range, g, g_range, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
 }
 
-int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const void* g, int g_packed, const uint32_t* g_range, float* gw,
                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream) {
     if (x_range == nullptr || g_range == nullptr) return DASV_E_NULL;
-    return wgrad_launch(4, static_cast<const float*>(x_packed), x_range, g, g_range, gw, workspace, workspace_bytes, B, H, W, Cin, Cout, stream);
+    return wgrad_launch(g_packed ? 5 : 4, static_cast<const float*>(x_packed), x_range, static_cast<const float*>(g), g_range, gw, workspace,
+                        workspace_bytes, B, H, W, Cin, Cout, stream);
 }
 
 static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
@@ -662,7 +673,14 @@ static int wgrad_launch(int mode, const float* x, const uint32_t* x_range, const
         hipLaunchKernelGGL((dasv::conv3x3_wgrad_kernel<SP, NXV, PT __VA_OPT__(,) __VA_ARGS__>), grid, block, lds, s, p); \
     } while (0)
     if (nx > 15) return DASV_E_SHAPE;   // maps wider than 80 columns
-    if (mode == 4) {       // split8, x packed
+    if (mode == 5) {       // split8, x and g packed
+        if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1, true, true, true);
+        else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2, true, true, true);
+        else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2, true, true, true);
+        else if (nx <= 8) DASV_LAUNCH_WGRAD(false, 8, 0, true, true, true);
+        else if (nx <= 10) DASV_LAUNCH_WGRAD(false, 10, 0, true, true, true);
+        else DASV_LAUNCH_WGRAD(false, 15, 0, true, true, true);
+    } else if (mode == 4) {       // split8, x packed
         if (p.patch == 1) DASV_LAUNCH_WGRAD(false, 7, 1, true, true);
         else if (p.patch == 2 && nx <= 7) DASV_LAUNCH_WGRAD(false, 7, 2, true, true);
         else if (p.patch == 2) DASV_LAUNCH_WGRAD(false, 10, 2, true, true);

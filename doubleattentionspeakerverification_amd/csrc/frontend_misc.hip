@@ -239,7 +239,11 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
 __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                   float* __restrict__ gx, int H, int W, int C, int Ho, int Wo,
                                                                   long long nvec, int relu_mask, float* __restrict__ colsum,
-                                                                  const uint8_t* __restrict__ idx, const int* __restrict__ pool_src) {
+                                                                  const uint8_t* __restrict__ idx, const int* __restrict__ pool_src,
+                                                                  const uint32_t* __restrict__ gy_rec, uint32_t* __restrict__ gx_rec) {
+    // gy_rec / gx_rec (both or neither; dense batches): gx is written as a PACKED tensor (dasv_common.hpp, store_x8) scaled by the
+    // exponent of gy's recorded maximum — the scattered gradient has the same maximum — and gx_rec receives {that maximum, the exponent}:
+    // the data-gradient and weight-gradient launches that consume gx then copy its pieces instead of converting fp32 values
     // pool_src (ragged batch: B == 1, H = total input rows, Ho = total output rows): {first input row, has-second-row} per output row
     // idx (optional): the forward pass's {arg-max | 4 if maximum > 0} bytes — x is then not read (x may be null)
     // colsum (optional): [gridDim.x][C] per-channel sums of the gradient this workgroup scattered (= the bias gradient of
@@ -247,6 +251,13 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
     __shared__ f4 red[256];
     f4 csum = {0.f, 0.f, 0.f, 0.f};
     const int cq = C >> 2;
+    float sp = 1.f;
+    if (gx_rec != nullptr) {
+        const uint32_t ga = gy_rec[0];
+        const int Eg = x8_exp_for(ga);
+        sp = x8_pow2(Eg);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { gx_rec[0] = ga; gx_rec[1] = (uint32_t)Eg; }
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
         const long long op = i / cq;
@@ -293,10 +304,18 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
             r0[c] = arg[c] == 0 ? g[c] : 0.f; r1[c] = arg[c] == 1 ? g[c] : 0.f;
             r2[c] = arg[c] == 2 ? g[c] : 0.f; r3[c] = arg[c] == 3 ? g[c] : 0.f;
         }
-        *reinterpret_cast<f4*>(gx + base) = r0;
-        if (hw) *reinterpret_cast<f4*>(gx + o1) = r1;
-        if (hh) *reinterpret_cast<f4*>(gx + o2) = r2;
-        if (hw && hh) *reinterpret_cast<f4*>(gx + o3) = r3;
+        if (gx_rec != nullptr) {
+            const long long p0 = ((long long)b * H + h0) * W + w0;
+            store_x8(gx, p0, C, q * 4, r0, sp);
+            if (hw) store_x8(gx, p0 + 1, C, q * 4, r1, sp);
+            if (hh) store_x8(gx, p0 + W, C, q * 4, r2, sp);
+            if (hw && hh) store_x8(gx, p0 + W + 1, C, q * 4, r3, sp);
+        } else {
+            *reinterpret_cast<f4*>(gx + base) = r0;
+            if (hw) *reinterpret_cast<f4*>(gx + o1) = r1;
+            if (hh) *reinterpret_cast<f4*>(gx + o2) = r2;
+            if (hw && hh) *reinterpret_cast<f4*>(gx + o3) = r3;
+        }
         csum += g;   // exactly one of the window's inputs received g
     }
     if (colsum != nullptr) {
@@ -650,7 +669,9 @@ static long long maxpool_bwd_blocks_out(long long out_rows, int W, int C) {
 
 static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
                               float* colsum, dasv_stream_t stream, const uint8_t* idx = nullptr, const int* pool_src = nullptr,
-                              int rows_out = 0) {
+                              int rows_out = 0, const uint32_t* gy_rec = nullptr, uint32_t* gx_rec = nullptr) {
+    if ((gy_rec == nullptr) != (gx_rec == nullptr)) return DASV_E_NULL;
+    if (gx_rec != nullptr && (C % 64 != 0 || pool_src != nullptr)) return DASV_E_SHAPE;
     if (colsum != nullptr && (C / 4 > 256 || 256 % (C / 4) != 0)) return DASV_E_SHAPE;
     if ((x == nullptr && idx == nullptr) || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
@@ -659,7 +680,7 @@ static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B,
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
     const long long blocks = pool_src != nullptr ? maxpool_bwd_blocks_out(rows_out, W, C) : maxpool_bwd_blocks(B, H, W, C);
     hipLaunchKernelGGL(dasv::maxpool2x2_bwd_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W,
-                       C, Ho, Wo, nvec, relu_mask, colsum, idx, pool_src);
+                       C, Ho, Wo, nvec, relu_mask, colsum, idx, pool_src, gy_rec, gx_rec);
     return (int)hipGetLastError();
 }
 
@@ -684,6 +705,13 @@ int dasv_maxpool2x2_ceil_bwd_idx_nhwc(const uint8_t* idx, const float* gy, float
                                       int H, int W, int C, dasv_stream_t stream) {
     if (idx == nullptr) return DASV_E_NULL;
     return maxpool_bwd_launch(nullptr, gy, gx, B, H, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx);
+}
+
+int dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc(const uint8_t* idx, const float* gy, const uint32_t* gy_range, void* gx_packed, uint32_t* gx_range,
+                                         float* colsum_partial, int relu_mask, int B, int H, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr || gy_range == nullptr || gx_range == nullptr) return DASV_E_NULL;
+    return maxpool_bwd_launch(nullptr, gy, static_cast<float*>(gx_packed), B, H, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx, nullptr, 0,
+                              gy_range, gx_range);
 }
 
 /* the training pool and its backward over a ragged batch (pool_src as in dasv_maxpool2x2_ceil_ragged_nhwc): utterances of different

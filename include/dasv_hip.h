@@ -368,19 +368,26 @@ int dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(const void* x, int x_packed, const u
  *                                 workspace as dasv_conv3x3_bias_relu_nhwc_ws (small batches; not with colsum_partial)
  *   dasv_conv3x3_wgrad_x8p_nhwc   the weight gradient with x packed (its pieces are parked in LDS as fetched: no conversion work
  *                                 in the producer waves; x_range[1] = the exponent the tensor was packed with). */
-int dasv_conv3x3_masked_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask_packed,
-                                 float* y, uint32_t* y_range, float* colsum_partial, void* workspace, size_t workspace_bytes, int B, int H,
-                                 int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_masked_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                 const void* mask_packed, float* y, uint32_t* y_range, float* colsum_partial, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+/*   dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc  the pool's backward writing the scattered gradient PACKED (scaled by the exponent of gy's
+ *                                 recorded maximum, which the scattered tensor shares; gx_range receives {maximum, exponent}): the
+ *                                 x operand of convX2's data gradient (x_packed above) and the g operand of its weight gradient
+ *                                 (g_packed below) are then copied, not converted */
+int dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc(const uint8_t* idx, const float* gy, const uint32_t* gy_range, void* gx_packed, uint32_t* gx_range,
+                                         float* colsum_partial, int relu_mask, int B, int H, int W, int C, dasv_stream_t stream);
 /* The data gradient of the SECOND layer with the FIRST layer's whole backward in its write-out pass (train.py:220 through CNNs.py:38-39 /
  * 72-73): conv11 has one input channel, so its weight gradient gw[c][tap] = sum_pix g1[pix][c] * mel[pix + tap] (g1 = this launch's
  * masked output) costs 9 FMAs per element while the tile is in hand, and its bias gradient is the column sum.  The gradient at
  * conv11's output (786 MB for a [64,300,80] batch) is then written and read by nobody.  c1_partial: [dasv_conv3x3_colsum_rows(3, B,
  * H, W, 0)][Cout][10] floats {nine taps, bias} per pixel tile; dasv_conv3x3_c1_bwd_reduce_parts sums the rows in a fixed order into
  * gw [Cout][1][3][3] and gb [Cout] (gb may be NULL).  mask: conv11's ReLU output, fp32 or packed (mask_packed). */
-int dasv_conv3x3_masked_c1_x8p_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask, int mask_packed,
-                                    const float* mel, float* c1_partial, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
+int dasv_conv3x3_masked_c1_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask,
+                                    int mask_packed, const float* mel, float* c1_partial, int B, int H, int W, int Cin, int Cout,
+                                    dasv_stream_t stream);
 int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, float* gb, int Cout, dasv_stream_t stream);
-int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const float* g, const uint32_t* g_range, float* gw,
+int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const void* g, int g_packed, const uint32_t* g_range, float* gw,
                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_c1_bias_relu_x8_nhwc(const float* x, const uint32_t* x_range, const float* w, const float* bias, void* y_packed,
                                       uint32_t* y_range, int B, int H, int W, int Cout, int relu, dasv_stream_t stream);
