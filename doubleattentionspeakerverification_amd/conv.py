@@ -50,11 +50,35 @@ def exact(cin, cout):
     return cin % 64 == 0 and cout % 128 == 0
 
 
+_REC_POOLS = {}      # (device, stream) -> [zeroed int32 [1024, 2] block, rows handed out]
+
+
 def new_ranges(device, n=1):
     """n zeroed RANGE RECORDS (include/dasv_hip.h): row i = (bits of max |v|, exponent of a packed tensor) of one activation
     tensor.  The split8 convolution scales its operand planes by its input's record — on the device, no host round trip — and
-    every forward kernel of the front-end fills the record of what it writes.  One allocation per forward pass."""
-    return torch.zeros((n, 2), dtype=torch.int32, device=device)
+    every forward kernel of the front-end fills the record of what it writes.
+    Rows of a zeroed block per (device, stream), each handed out once (a training step asks for ~20 records one at a time: one fill
+    launch per 1,024 of them instead of one each); under stream capture a fresh zeros() — a replayed graph must zero its records
+    itself."""
+    device = torch.device(device)
+    if device.type != "cuda" or n > 256 or torch.cuda.is_current_stream_capturing():
+        return torch.zeros((n, 2), dtype=torch.int32, device=device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    pool = _REC_POOLS.get(key)
+    if pool is None or pool[1] + n > pool[0].shape[0]:
+        pool = _REC_POOLS[key] = [torch.zeros((1024, 2), dtype=torch.int32, device=device), 0]
+    r = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return r
+
+
+def _sum_rows(part):
+    """[rows, C] per-workgroup column sums -> [C] (fixed order; dasv_colsum_reduce)."""
+    out = torch.empty(part.shape[1], dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.load().dasv_colsum_reduce(part.data_ptr(), part.shape[0], part.shape[1], out.data_ptr(),
+                                                  torch.cuda.current_stream(part.device).cuda_stream), "dasv_colsum_reduce")
+    return out
 
 
 def range_of(x):
@@ -206,7 +230,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                                                             y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
                                                             None if part is None else part.data_ptr(), span.data_ptr(), H, W, cin, cout, stream)
                 if part is not None and rc == 0:
-                    colsum["gb"] = part.sum(dim=0)
+                    colsum["gb"] = _sum_rows(part)
             else:
                 nws = lib.dasv_conv3x3_workspace_bytes(1, H, W, cin, cout)
                 ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
@@ -235,7 +259,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                                                   None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
                                                   None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, stream)
             if part is not None and rc == 0:
-                colsum["gb"] = part.sum(dim=0)
+                colsum["gb"] = _sum_rows(part)
         elif mode == "split8" and mask is not None:
             rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0) if colsum is not None else 0
             part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
@@ -243,7 +267,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                                                  None if y_rec is None else y_rec.data_ptr(), None if part is None else part.data_ptr(),
                                                  B, H, W, cin, cout, stream)
             if part is not None and rc == 0:
-                colsum["gb"] = part.sum(dim=0)
+                colsum["gb"] = _sum_rows(part)
         elif mode == "split8":
             nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
             ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
@@ -257,7 +281,7 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
             rc = lib.dasv_conv3x3_masked_nhwc(MODES[mode], x.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
                                               y.data_ptr(), None if part is None else part.data_ptr(), B, H, W, cin, cout, stream)
             if part is not None and rc == 0:
-                colsum["gb"] = part.sum(dim=0)
+                colsum["gb"] = _sum_rows(part)
         else:
             # small maps (single utterances): split-K over the channel slabs, partial tiles in a workspace
             nws = lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
@@ -521,7 +545,7 @@ class _ConvReLUPoolFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         g, g_rec, part = _pool_scatter(idx, gy, B, H, W, C, ctx.has_bias, packed=ctx.x_packed)
         if part is not None:
-            ctx.link_in["gb"] = part.sum(dim=0)
+            ctx.link_in["gb"] = _sum_rows(part)
         return _conv_backward(ctx, x, weight, g, g_rec, C, g_packed=ctx.x_packed) + (None,) * 8
 
 
@@ -565,7 +589,7 @@ class _FirstBlockFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             gw12 = conv3x3_wgrad(h, g, "split8", x_rec=ctx.h_rec, g_rec=g_rec, x_packed=True, g_packed=True) if ctx.needs_input_grad[3] else None
-            gb12 = part.sum(dim=0) if part is not None and ctx.needs_input_grad[4] else None
+            gb12 = _sum_rows(part) if part is not None and ctx.needs_input_grad[4] else None
             gw11 = gb11 = None
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 hi, lo = _pack_dgrad_x8(w12.detach())
@@ -900,7 +924,7 @@ class _MaxPoolFn(torch.autograd.Function):
                                                                   None if part is None else part.data_ptr(), int(bool(ctx.relu_input)),
                                                                   ctx.pool_src.data_ptr(), H, int(ctx.pool_src.shape[0]), W, C, stream)
             if part is not None and rc == 0:
-                ctx.link_out["gb"] = part.sum(dim=0)
+                ctx.link_out["gb"] = _sum_rows(part)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
         rec = _rec_of(gy)
         if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)

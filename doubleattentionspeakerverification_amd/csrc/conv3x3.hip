@@ -167,9 +167,11 @@ __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const floa
     if (tid == 0) {
         aux[o * 4 + 0] = (uint8_t)(127 - el); aux[o * 4 + 1] = (uint8_t)(127 - eh); aux[o * 4 + 2] = 0; aux[o * 4 + 3] = 0;
         winv[o] = x8_pow2(-Ew);
-        atomicMax(tail, __float_as_uint(l1) & 0x7fffffffu);
+        if (!transposed) atomicMax(tail, __float_as_uint(l1) & 0x7fffffffu);
+        // (data-gradient planes: no launch scales a packed OUTPUT by them — NaN bounds instead of a memset and Cout atomics per step)
+        else if (o == 0) { tail[0] = 0x7fc00000u; tail[1] = 0x7fc00000u; }
     }
-    if (o == 0) {
+    if (o == 0 && !transposed) {
         float mb = 0.f;
         uint32_t bb = 0u;
         if (bias != nullptr)
@@ -1726,8 +1728,6 @@ int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3
     if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0 || Cout % 64 != 0) return DASV_E_SHAPE;
     // planes of the convolution with Cin outputs and Cout inputs
-    hipError_t e = hipMemsetAsync(static_cast<char*>(w_e4m3) + (size_t)Cin * 9 * Cout * 2 + (size_t)Cin * 8, 0, 16, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, w, nullptr,
                        static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 1);
     return (int)hipGetLastError();

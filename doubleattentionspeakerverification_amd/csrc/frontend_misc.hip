@@ -416,20 +416,49 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __rest
     }
 }
 
-// 16 lanes per output value: lane j sums partial rows j, j+16, ... (fixed order), then a DPP butterfly over the 16 lanes —
-// deterministic, and a few thousand partial rows cost microseconds instead of one long serial loop per thread
+// One workgroup per four consecutive (n, t) values: thread j sums partial rows j, j + 256, ... (independent 16-byte loads), then a tree
+// over the 256 partial sums — fixed order.  (Round 3's form, 16 lanes per value, was latency-bound once the partial rows came from
+// conv12's 6,080 patch tiles: ~380 dependent round trips per lane.)
 __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __restrict__ part, float* __restrict__ gw,
                                                              float* __restrict__ gb, int nblk, int Cout) {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // (n, t) with t in 0..9
-    const int j = threadIdx.x & 15;
-    float v = 0.f;
-    if (i < Cout * 10)
-        for (int k = j; k < nblk; k += 16) v += part[(size_t)k * Cout * 10 + i];
-    v = group_sum<16>(v);
-    if (i >= Cout * 10 || j != 0) return;
-    const int n = i / 10, t = i - n * 10;
-    if (t < 9) gw[n * 9 + t] = v;
-    else if (gb != nullptr) gb[n] = v;
+    __shared__ f4 red[256];
+    const int i0 = blockIdx.x * 4, tid = threadIdx.x;           // values i0 .. i0 + 3 of the [Cout][10] row
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = tid; k < nblk; k += 256) v += *reinterpret_cast<const f4*>(part + (size_t)k * Cout * 10 + i0);
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) red[tid] += red[tid + sft];
+        __syncthreads();
+    }
+    if (tid < 4) {
+        const int i = i0 + tid, n = i / 10, t = i - n * 10;
+        const float r = red[0][tid];
+        if (t < 9) gw[n * 9 + t] = r;
+        else if (gb != nullptr) gb[n] = r;
+    }
+}
+
+// out[c] = sum_k part[k][c], fixed order — the per-workgroup column sums the pool's backward and the masked data-gradient launches leave
+// behind (bias gradients), a few thousand rows.  One workgroup per four columns: thread t adds rows t, t + 256, ... (independent 16-byte
+// loads, a handful of round trips), then a tree over the 256 partial sums.  (16 lanes per column looping over ~500 rows each was
+// latency-bound: 0.2-0.5 ms per call.)
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int rows, int C) {
+    __shared__ f4 red[256];
+    const int c0 = blockIdx.x * 4, tid = threadIdx.x;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = tid; k < rows; k += 256) v += *reinterpret_cast<const f4*>(part + (size_t)k * C + c0);
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) red[tid] += red[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) *reinterpret_cast<f4*>(out + c0) = red[0];
 }
 
 // Border tables of a ragged batch (ragged.py), made on the device from the utterance lengths alone: blockIdx.y = table
@@ -757,11 +786,18 @@ int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float*
     return c1_bwd_launch(x, y, gy, gw, gb, workspace, workspace_bytes, 1, rows, W, Cout, stream, row_span);
 }
 
+int dasv_colsum_reduce(const float* partial, int rows, int C, float* out, dasv_stream_t stream) {
+    if (partial == nullptr || out == nullptr) return DASV_E_NULL;
+    if (rows <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
+    hipLaunchKernelGGL(dasv::colsum_reduce_kernel, dim3((unsigned)(C / 4)), dim3(256), 0, (hipStream_t)stream, partial, out, rows, C);
+    return (int)hipGetLastError();
+}
+
 int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, float* gb, int Cout, dasv_stream_t stream) {
     if (partial == nullptr || gw == nullptr) return DASV_E_NULL;
     if (rows <= 0 || Cout <= 0) return DASV_E_SHAPE;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, gw,
-                       gb, rows, Cout);
+    if (Cout % 2 != 0) return DASV_E_SHAPE;
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)(Cout * 10 / 4)), dim3(256), 0, (hipStream_t)stream, partial, gw, gb, rows, Cout);
     return (int)hipGetLastError();
 }
 
@@ -783,7 +819,7 @@ static int c1_bwd_launch(const float* x, const float* y, const float* gy, float*
                        pix_per_block, row_span);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 * 16 + 255) / 256)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)(Cout * 10 / 4)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
     return (int)hipGetLastError();
 }
 

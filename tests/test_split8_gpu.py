@@ -351,7 +351,7 @@ def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin):
     """dasv_conv3x3_pack_weights_x8_dgrad: the split8 planes of a layer's data-gradient convolution (train.py:220; the weights
     transposed over (out, in) and flipped over (ky, kx)) packed straight from the layer's weight must be the planes
     dasv_conv3x3_pack_weights_x8 makes from an explicitly transposed and flipped copy — byte for byte (fp16 plane, e4m3 planes, scale
-    bytes, channel scales); the L1 bound behind them is summed in another order (last-bit differences)."""
+    bytes, channel scales)."""
     from doubleattentionspeakerverification_amd import conv
     w = torch.from_numpy(rnd(17, cout, cin, 3, 3, scale=0.05)).to(DEV)
     w[3, 5] *= 1e4                                      # channels of very different magnitude: per-channel scales
@@ -362,8 +362,8 @@ def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin):
     assert torch.equal(hi[:n_planes], hi2[:n_planes])
     body = n_planes + cin * 8                           # e4m3 planes | [cin][4] scale bytes | [cin] floats 2^-Ew
     assert torch.equal(lo[:body], lo2[:body])
-    t1, t2 = lo[body:body + 8].view(torch.float32), lo2[body:body + 8].view(torch.float32)
-    assert abs(float(t1[0]) - float(t2[0])) <= 1e-5 * float(t2[0]) and float(t1[1]) == 0.0
+    # (the two output bounds behind them — what a PACKED output would be scaled by — are not made for data-gradient planes: NaN)
+    assert bool(torch.isnan(lo[body:body + 8].view(torch.float32)).all())
 
 
 @pytest.mark.parametrize("cin,cout,H,W,B", [(64, 128, 9, 7, 3), (128, 128, 38, 10, 5), (64, 128, 33, 80, 2), (64, 128, 1, 1, 2),
