@@ -1375,6 +1375,15 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 amax_u = wave_umax(amax_u);
                 if (lane == 0 && amax_u > rec_seen) atomicMax(&s_amax, amax_u);
             }
+            // (first-layer backward in the write-out pass, patch tiles: the 18 x 18 window of the input features behind the image —
+            // the nine taps of every pixel then come out of LDS instead of nine cache reads in the exposed epilogue)
+            float* melw = reinterpret_cast<float*>(smem + TBM * OP);
+            if constexpr (X8 && GEOM == 1) {
+                if (p.c1_part != nullptr && tid < PW * PW) {
+                    const int r = tid / PW, c = tid - r * PW, hh = gh0 - 1 + r, ww = gw0 - 1 + c;
+                    melw[tid] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? p.c1_mel[((size_t)gb * H + hh) * W + ww] : 0.f;
+                }
+            }
             __syncthreads();
             DASV_STAMP(62);
             if (p.y_rec != nullptr && tid == 0 && s_amax > rec_seen) atomicMax(p.y_rec, s_amax);
@@ -1524,15 +1533,19 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                         csum += v;
                         if constexpr (X8) {
                             if (c1f) {
-                                int h_, w_;
-                                if constexpr (GEOM == 1) { h_ = gh0 + (pix >> 4); w_ = gw0 + (pix & 15); }
-                                else { w_ = mm[k] % W; h_ = (mm[k] / W) % H; }
-                                const float* mp = p.c1_mel + mm[k];
+                                if constexpr (GEOM == 1) {
+                                    const float* mw = melw + (pix >> 4) * PW + (pix & 15);
 #pragma unroll
-                                for (int t = 0; t < 9; ++t) {
-                                    const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-                                    const float in = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? mp[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
-                                    wacc[t] += v * in;
+                                    for (int t = 0; t < 9; ++t) wacc[t] += v * mw[(t / 3) * PW + t % 3];
+                                } else {
+                                    const int w_ = mm[k] % W, h_ = (mm[k] / W) % H;
+                                    const float* mp = p.c1_mel + mm[k];
+#pragma unroll
+                                    for (int t = 0; t < 9; ++t) {
+                                        const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
+                                        const float in = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? mp[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                                        wacc[t] += v * in;
+                                    }
                                 }
                             }
                         }
