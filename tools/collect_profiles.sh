@@ -18,7 +18,7 @@ TRAIN="python3 bench.py --workload train --steps 3 --warmup 2 --regions 1 --no-c
 echo "== pmc MfmaUtil: embed" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/embed_mfma -- $EMBED > $OUT/embed_mfma.log 2>&1 || tail -5 $OUT/embed_mfma.log
 echo "== pmc MfmaUtil: train" && rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/train_mfma -- $TRAIN > $OUT/train_mfma.log 2>&1 || tail -5 $OUT/train_mfma.log
 echo "== kernel trace: train" && rocprofv3 --kernel-trace --output-format csv -d $OUT/train_trace -- $TRAIN > $OUT/train_trace.log 2>&1 || tail -5 $OUT/train_trace.log
-f=$(find $OUT/train_trace -name "*kernel_trace.csv" | head -1) && python3 tools/train_step_mix.py $f $OUT/train_step_mix.md > /dev/null
+f=$(find $OUT/train_trace -name "*kernel_trace.csv" | head -1) && python3 tools/train_step_mix.py $f $OUT/train_step_mix.md > /dev/null && python3 tools/train_step_seq.py $f $OUT/train_step_sequence.txt > /dev/null
 echo "== power test (random vs all-zero data, same launches)" && timeout -k 10 200 python3 tools/_diag/conv_power_test.py > $OUT/conv_power_test.log 2>&1 || tail -3 $OUT/conv_power_test.log
 echo "== wgrad forms" && timeout -k 10 200 python3 tools/_diag/wgrad_x8_ab.py > $OUT/wgrad_x8_ab.log 2>&1 || tail -3 $OUT/wgrad_x8_ab.log
 echo "== conv tile stamps" && timeout -k 10 200 python3 tools/conv_stamps.py run > $OUT/conv_stamps.log 2>&1 || tail -3 $OUT/conv_stamps.log

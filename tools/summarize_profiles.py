@@ -174,6 +174,9 @@ for name, title in (("train_step_mix.md", None), ("conv_power_test.log", "power 
     if title is None:
         open(os.path.join(dst, "%s_%s" % (tag, name)), "w").write(text)
         md.append("\n## steady-state training step\n\n" + text)
+        seq = os.path.join(src, "train_step_sequence.txt")
+        if os.path.exists(seq):      # every kernel of that step in launch order (tools/train_step_seq.py)
+            open(os.path.join(dst, "%s_train_step_sequence.txt" % tag), "w").write(open(seq).read())
     else:
         md.append("\n## %s\n\n```\n%s```\n" % (title, text))
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
