@@ -101,6 +101,23 @@ class ConvTimer:
             self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))
             return y
         convmod._launch = timed
+        # the packed training chain's other two launch sites: conv + ReLU + pool with arg-max bytes, and conv12's data gradient with
+        # conv11's backward in its write-out pass (both: x [B, cin, H, W], cout as fifth argument)
+        for name in ("_launch_pool_idx", "_launch_dgrad_c1"):
+            def wrap(inner_fn):
+                def timed_fn(x, hi, lo, a4, a5, *a, **k):
+                    if not self.active:
+                        return inner_fn(x, hi, lo, a4, a5, *a, **k)
+                    cout = a5 if inner_fn.__name__ == "_launch_pool_idx" else a4
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record(torch.cuda.current_stream(x.device))
+                    y = inner_fn(x, hi, lo, a4, a5, *a, **k)
+                    e.record(torch.cuda.current_stream(x.device))
+                    B, cin, H, W = x.shape
+                    self.rec.append((s, e, 2.0 * 9 * cin * cout * B * H * W))
+                    return y
+                return timed_fn
+            setattr(convmod, name, wrap(getattr(convmod, name)))
         inner8 = convmod.conv3x3_x8       # the packed-activation inference chain (CNNs._forward_map_packed) launches through this one
 
         def timed8(x, weight, *a, **k):
@@ -747,8 +764,9 @@ def main():
                     "matrix_pipe_time_per_algorithmic_flop_in_bf16_mfma_units": wmult,
                     "mfma_executed_frac": round(wtfs * wmult / MFMA_BF16_PEAK_TFS, 4),
                     "note": "each 64 x 64 tile streams its g and x channels for every pixel: the launch moves Cout/64 x |x| + Cin/64 x |g| "
-                            "bytes through the L2 (3.1 GB for conv12) and is held by that and by its producers' conversion, not by the "
-                            "matrix pipe (DESIGN.md 4.4b)"}
+                            "bytes through the L2 (3.1 GB for conv12); in the packed training chain the producer waves copy x (and, behind a "
+                            "pool, g) instead of converting them, and the launch is held by its transposed LDS reads (~85 % of the matrix "
+                            "pipe's time per chunk) — DESIGN.md 4.4b, 4.4i"}
             if world == 1 and args.workload == "embed" and args.conv == "split8" and not args.no_power_probe:
                 roofline["power_probe"] = conv_power_probe(dev, B)
         # companions (never the headline `value`): the same step with the other operand modes of the convolutions, each with its

@@ -19,7 +19,7 @@ LIBNAME = "libdasv_hip.so"
 # this second library; the product library exports none of it
 DEBUG_LIBNAME = "libdasv_hip_dbg.so"
 DEBUG_SOURCES = ["dmha_fwd.hip", "conv3x3.hip"]        # the translation units that contain DASV_DEBUG code
-SOURCES = ["dmha_fwd.hip", "dmha_bwd.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "frontend_misc.hip", "amsoftmax.hip"]
+SOURCES = ["dmha_fwd.hip", "dmha_bwd.hip", "conv3x3.hip", "conv3x3_wgrad.hip", "frontend_misc.hip", "amsoftmax.hip", "adam.hip"]
 HEADERS = ["dasv_common.hpp", os.path.join("..", "..", "include", "dasv_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -478,6 +478,37 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p, g_packed=False):
     return gx, gw, gb
 
 
+def _launch_pool_idx(x, hi, lo, bias, cout, x_rec, y_rec, x_packed, y_packed):
+    """conv3x3 + bias + ReLU + 2x2 ceil max-pool in one launch, training form: (pooled map, arg-max bytes)."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                         None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
+                                                         None if y_rec is None else y_rec.data_ptr(), idx.data_ptr(), B, H, W, cin, cout,
+                                                         torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
+    return y, idx
+
+
+def _launch_dgrad_c1(g, hi, lo, cout, g_rec, mask, mel):
+    """conv12's data-gradient launch (g packed, mask = conv11's packed output) with conv11's backward in its write-out pass:
+    the per-tile partial rows [tiles][cout][10]."""
+    lib = _lib.load()
+    B, cin, H, W = g.shape
+    rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0)
+    cpart = torch.empty((rows, cout, 10), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), 1,
+                                                 mel.data_ptr(), cpart.data_ptr(), B, H, W, cin, cout,
+                                                 torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_masked_c1_x8p_nhwc")
+    return cpart
+
+
 def _pool_scatter(idx, gy, B, H, W, C, want_sum, packed):
     """The pool's backward from the forward's arg-max bytes (which carry the ReLU's mask too): (g [B,C,H,W], its range record or None,
     per-workgroup column sums or None).  packed: g is written as a PACKED tensor scaled by the exponent of gy's maximum (the
@@ -513,21 +544,10 @@ class _ConvReLUPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mask_input_grad, link_out, x_rec, y_rec, fresh=True, x_packed=False, y_packed=False):
-        lib = _lib.load()
-        cout, cin = weight.shape[0], weight.shape[1]
-        B, cin_x, H, W = x.shape
         hi, lo = packed.get(weight, "split8", bias, fresh=fresh)
         if x_rec is None:
             x_rec = range_of(x)
-        Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        y = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        idx = torch.empty((B, Ho, Wo, cout), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
-            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                                             None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
-                                                             None if y_rec is None else y_rec.data_ptr(), idx.data_ptr(), B, H, W, cin_x, cout,
-                                                             torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
+        y, idx = _launch_pool_idx(x, hi, lo, bias, weight.shape[0], x_rec, y_rec, x_packed, y_packed)
         ctx.save_for_backward(x, weight, idx)
         ctx.x_rec, ctx.has_bias, ctx.mode = x_rec, bias is not None, "split8"
         ctx.grad_premasked, ctx.mask_input_grad = True, mask_input_grad
@@ -558,20 +578,9 @@ class _FirstBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, y_packed, fresh):
-        lib = _lib.load()
         h = conv3x3_c1_bias_relu(mel, w11, b11, pack=True, x_rec=x_rec, y_rec=h_rec)
-        B, C1, H, W = h.shape
-        C2 = w12.shape[0]
         hi, lo = packed12.get(w12, "split8", b12, fresh=fresh)
-        Ho, Wo = (H + 1) // 2, (W + 1) // 2
-        y = torch.empty((B, C2, Ho, Wo), dtype=torch.float32, device=h.device, memory_format=torch.channels_last)
-        idx = torch.empty((B, Ho, Wo, C2), dtype=torch.uint8, device=h.device)
-        with torch.cuda.device(h.device):
-            rc = lib.dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(h.data_ptr(), 1, h_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                                             None if b12 is None else b12.data_ptr(), y.data_ptr(), int(y_packed),
-                                                             y_rec.data_ptr(), idx.data_ptr(), B, H, W, C1, C2,
-                                                             torch.cuda.current_stream(h.device).cuda_stream)
-        _lib.check(rc, "dasv_conv3x3_bias_relu_pool_idx_x8_nhwc")
+        y, idx = _launch_pool_idx(h, hi, lo, b12, w12.shape[0], h_rec, y_rec, True, y_packed)
         ctx.save_for_backward(mel.contiguous(), h, w12, idx)
         ctx.h_rec, ctx.bias = h_rec, (b11 is not None, b12 is not None)
         ctx.w11_shape = w11.shape
@@ -593,11 +602,8 @@ class _FirstBlockFn(torch.autograd.Function):
             gw11 = gb11 = None
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 hi, lo = _pack_dgrad_x8(w12.detach())
-                prow = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0)
-                cpart = torch.empty((prow, C1, 10), dtype=torch.float32, device=dev)
-                _lib.check(lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), h.data_ptr(), 1,
-                                                               mel.data_ptr(), cpart.data_ptr(), B, H, W, C2, C1, st),
-                           "dasv_conv3x3_masked_c1_x8p_nhwc")
+                cpart = _launch_dgrad_c1(g, hi, lo, C1, g_rec, h, mel)
+                prow = cpart.shape[0]
                 gw11 = torch.empty(ctx.w11_shape, dtype=torch.float32, device=dev)
                 gb11 = torch.empty(C1, dtype=torch.float32, device=dev) if ctx.bias[0] else None
                 _lib.check(lib.dasv_conv3x3_c1_bwd_reduce_parts(cpart.data_ptr(), prow, gw11.data_ptr(), None if gb11 is None else gb11.data_ptr(),

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-__all__ = ["init_distributed", "FlatGradReducer", "DataParallelTrainer", "shard_batch"]
+__all__ = ["init_distributed", "FlatGradReducer", "FlatAdam", "DataParallelTrainer", "shard_batch"]
 
 
 def init_distributed(backend=None):
@@ -69,6 +69,7 @@ class FlatGradReducer:
             offs[i] = total
             total += (sizes[i] + 63) // 64 * 64
         self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.offs, self.sizes = offs, sizes      # slot of parameter i: flat[offs[i] : offs[i] + sizes[i]] (FlatAdam shares the layout)
         self.buckets = []  # (lo, hi, [param indices])
         cap = max(1, bucket_bytes // 4)
         lo, members = 0, []
@@ -204,8 +205,9 @@ class FlatGradReducer:
         """What the caller multiplies its (mean) loss by so that the summed buffers hold the global-batch mean's gradient."""
         return 1.0 / self.world
 
-    def zero(self):
-        self.flat.zero_()
+    def zero(self, flat_cleared=False):
+        if not flat_cleared:         # (FlatAdam clears the gradient buffer in its own pass)
+            self.flat.zero_()
         for buf in self._cold_bufs:
             buf.zero_()
         self._fired = [False] * len(self.params)
@@ -223,11 +225,80 @@ class FlatGradReducer:
             self.params[i].grad = self.views[i]
 
 
+class FlatAdam:
+    """`optim.Adam(net.parameters(), lr, weight_decay)` of train.py:82-84 as ONE hand-written launch per step (csrc/adam.hip,
+    dasv_adam_step_f32): parameters, gradients (FlatGradReducer's buffer) and both moments share one flat layout, so `optimizer.step()`
+    (train.py:224) is a single pass over 4 x 86 MB that also clears the gradient buffer.  The parameters of the module are re-pointed at
+    views of the flat parameter buffer (same values, same shapes: state_dict / checkpoints are unaffected).  Parameters that received no
+    gradient are skipped — no update, no weight decay — like `grad is None` in the reference (model.py:46,50: b1.*, b3.*).
+    `param_groups[0]` carries lr / weight_decay / betas / eps and is read at every step (a scheduler or train.py's manual decay may
+    rewrite it).  GPU only; torch's arithmetic."""
+
+    def __init__(self, reducer, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.reducer = reducer
+        flat = reducer.flat
+        if not flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the GPU only (libdasv_hip.so); use torch.optim.Adam on the CPU")
+        self.p = torch.zeros_like(flat)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+        with torch.no_grad():
+            for i, prm in enumerate(reducer.params):
+                view = self.p[reducer.offs[i]:reducer.offs[i] + reducer.sizes[i]].view_as(prm)
+                view.copy_(prm)
+                prm.data = view
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": tuple(betas), "eps": eps}]
+        self.step_count = 0
+        self._active_key, self._active = None, None
+
+    def _active_blocks(self, hidden):
+        key = frozenset(hidden)
+        if key != self._active_key:
+            act = torch.ones(self.p.numel() // 64, dtype=torch.uint8)
+            for i in hidden:
+                lo = self.reducer.offs[i] // 64
+                act[lo:lo + (self.reducer.sizes[i] + 63) // 64] = 0
+            self._active, self._active_key = act.to(self.p.device), key
+        return self._active
+
+    def step(self, hidden=()):
+        """hidden: indices (into reducer.params) of the parameters without a gradient this step (FlatGradReducer.hide_unused).  Clears
+        the reducer's flat gradient buffer."""
+        from . import _lib
+        r = self.reducer
+        hidden = set(hidden)
+        with torch.no_grad():
+            for i in r._cold:             # a retired parameter that fired after all: its gradient sits in a cold buffer
+                if i not in hidden:
+                    r.flat[r.offs[i]:r.offs[i] + r.sizes[i]].copy_(r.views[i].reshape(-1))
+        act = self._active_blocks(hidden)
+        g = self.param_groups[0]
+        self.step_count += 1
+        with torch.cuda.device(self.p.device):
+            rc = _lib.load().dasv_adam_step_f32(self.p.data_ptr(), r.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                act.data_ptr(), self.p.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                                float(g["eps"]), float(g["weight_decay"]), self.step_count, 1,
+                                                torch.cuda.current_stream(self.p.device).cuda_stream)
+        _lib.check(rc, "dasv_adam_step_f32")
+
+    def zero_grad(self, set_to_none=False):
+        self.reducer.zero()
+
+    def state_dict(self):
+        return {"flat_adam": True, "step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
 class DataParallelTrainer:
     """One training step per call, with the reference's step semantics (train.py:186-198, 215-226)."""
 
     def __init__(self, net, lr=1e-4, weight_decay=1e-3, optimizer="Adam", accum=1, bucket_bytes=32 << 20,
-                 autocast_dtype=None, group=None):
+                 autocast_dtype=None, group=None, flat_adam=True):
         self.net = net
         self.accum = int(accum)
         self.autocast_dtype = autocast_dtype
@@ -238,7 +309,9 @@ class DataParallelTrainer:
         self.reducer = FlatGradReducer(net.parameters(), bucket_bytes=bucket_bytes, group=group)
         params = list(net.parameters())
         on_gpu = params[0].is_cuda
-        if optimizer == "Adam":
+        if optimizer == "Adam" and on_gpu and flat_adam and all(p.dtype == torch.float32 for p in params):
+            self.opt = FlatAdam(self.reducer, lr=lr, weight_decay=weight_decay)      # one hand-written launch per step
+        elif optimizer == "Adam":
             self.opt = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=on_gpu)
         elif optimizer == "SGD":
             self.opt = torch.optim.SGD(params, lr=lr, weight_decay=weight_decay)
@@ -298,11 +371,15 @@ class DataParallelTrainer:
         if last:
             self.reducer.finish()
             hidden = self.reducer.hide_unused()
-            self.opt.step()
+            own = isinstance(self.opt, FlatAdam)
+            if own:
+                self.opt.step(hidden)
+            else:
+                self.opt.step()
             # (the fused optimizers do not move the parameters' version counters: packed copies of the convolution weights made by
             # a no-grad forward before this step must not survive it)
             from .conv import invalidate_packed_weights
             invalidate_packed_weights(self.net)
             self.reducer.restore(hidden)
-            self.reducer.zero()  # grads are views of the flat buffer: one memset instead of zero_grad()
+            self.reducer.zero(flat_cleared=own)  # grads are views of the flat buffer: one memset (or none) instead of zero_grad()
         return loss.detach(), costh.detach()

@@ -491,6 +491,18 @@ int dasv_debug_read_floor(const void* x, size_t bytes, float* scratch, dasv_stre
 void dasv_debug_conv_patch_tiles(int on);
 #endif /* DASV_DEBUG */
 
+/* ------------------------------------------------------------------------
+ * The optimizer step of the training loop (train.py:224 `optimizer.step()` with train.py:82-84 `optim.Adam(net.parameters(), lr,
+ * weight_decay)`) over FLAT fp32 buffers: parameters, gradients and both moments share one layout of 64-element-aligned
+ * slots (dist.FlatGradReducer's), so the whole model is one HBM pass.  torch's Adam arithmetic: grad += weight_decay * param;
+ * exp_avg = b1 exp_avg + (1 - b1) grad; exp_avg_sq = b2 exp_avg_sq + (1 - b2) grad^2; param -= lr / (1 - b1^step) * exp_avg /
+ * (sqrt(exp_avg_sq) / sqrt(1 - b2^step) + eps).  active_blocks (optional): one byte per 64 elements, 0 = leave that block alone —
+ * parameters that received no gradient get no update and no weight decay, as with `grad is None` in the reference (model.py:46,50:
+ * b1.*, b3.*).  zero_grad: clear the gradient on the way (the next step accumulates into it).  n % 64 == 0, step >= 1.
+ * ------------------------------------------------------------------------ */
+int dasv_adam_step_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active_blocks, long long n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, long long step, int zero_grad, dasv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

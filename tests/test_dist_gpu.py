@@ -69,3 +69,46 @@ def test_bucketed_async_rccl_allreduce_from_autograd_hooks():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_flat_adam_equals_torch_adam_over_several_steps_and_skips_parameters_without_gradients():
+    """dist.FlatAdam (csrc/adam.hip: ONE launch over flat parameter / gradient / moment buffers — SURVEY 8f-2, train.py:82-84,224)
+    against `torch.optim.Adam(params, lr, weight_decay)` on the same gradients: six steps with a learning rate rewritten in
+    `param_groups` half way (train.py's manual decay), a parameter that never receives a gradient (no update, no weight decay, like
+    `grad is None`: model.py:46,50), odd sizes (64-element slots), the gradient buffer cleared by the step, and the module's
+    parameters living in the flat buffer afterwards (state_dict values unchanged by the re-pointing)."""
+    from doubleattentionspeakerverification_amd.dist import FlatAdam, FlatGradReducer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(37, 5, 3, 3), (129,), (64, 64), (1,), (1000, 33)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device=dev) * (0.1 + i)) for i, s in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    before = [p.detach().clone() for p in ps]
+    red = FlatGradReducer(ps, bucket_bytes=1 << 12)
+    opt = FlatAdam(red, lr=3e-3, weight_decay=1e-2)
+    assert all(torch.equal(a, b) for a, b in zip(ps, before))                        # re-pointed, same values
+    assert all(p.data_ptr() >= opt.p.data_ptr() and p.data_ptr() < opt.p.data_ptr() + opt.p.numel() * 4 for p in ps)
+    topt = torch.optim.Adam(ref, lr=3e-3, weight_decay=1e-2)
+    for step in range(6):
+        if step == 3:
+            opt.param_groups[0]["lr"] = topt.param_groups[0]["lr"] = 1e-3
+        hidden = []
+        for i, (p, q) in enumerate(zip(ps, ref)):
+            if i == 3:                         # never fires
+                hidden.append(i)
+                q.grad = None
+                continue
+            g = torch.randn_like(p) * (10.0 ** (step - 3))
+            p.grad.copy_(g)                    # (the reducer made p.grad a view of its flat buffer)
+            q.grad = g.clone()
+        opt.step(hidden)
+        topt.step()
+        assert float(red.flat.abs().sum()) == 0.0                                    # cleared on the way
+        for i, (p, q) in enumerate(zip(ps, ref)):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg="step %d param %d" % (step, i))
+    assert torch.equal(ps[3].detach(), before[3])                                    # untouched: no update, no weight decay
+    sd = opt.state_dict()
+    opt2 = FlatAdam(FlatGradReducer([torch.nn.Parameter(p.detach().clone()) for p in ps], bucket_bytes=1 << 12), lr=1.0, weight_decay=0.0)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 6 and torch.equal(opt2.exp_avg, opt.exp_avg) and opt2.param_groups[0]["lr"] == 1e-3
