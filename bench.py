@@ -357,12 +357,15 @@ def cpu_model():
 def companion_workloads():
     """BASELINE configs 3/4 and 5 inside the driver-timed line: after the headline's timed regions (never inside them, never in
     `value`), this script runs itself as a child process for the training step (`--workload train`: forward + AM-softmax/CE + backward +
-    Adam on [64,300,80], 5994 speakers) and for the variable-length pass on the fp16 MFMA path (`--workload varlen --conv fp16`: 1,024
+    Adam on [64,300,80], 5994 speakers; and the same on a minibatch of utterances of different lengths) and for the variable-length pass on
+    the fp16 MFMA path (`--workload varlen --conv fp16`: 1,024
     utterances of 150..800 frames, ragged packing), and keeps each child's value, step time and roofline.  The parent's GPU work is
     finished and synchronised before a child starts; a child that fails is reported as such, not hidden."""
     import subprocess
     out = {}
     runs = {"train (BASELINE config 3/4 on one GPU)": ["--workload", "train", "--steps", "20", "--warmup", "5", "--regions", "5"],
+            "train_varied_lengths (north_star: variable-length training minibatches, one GPU)":
+                ["--workload", "train", "--train-lengths", "varied", "--steps", "10", "--warmup", "3", "--regions", "3"],
             "varlen_fp16 (BASELINE config 5 on one GPU)": ["--workload", "varlen", "--conv", "fp16", "--steps", "3", "--warmup", "1", "--regions", "3"]}
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-companions", "--no-power-probe"] + extra
@@ -506,6 +509,8 @@ def main():
                     help="timed regions of --steps steps each (every one bracketed by barrier + synchronize); the line reports the "
                          "MEDIAN region, so ms_per_step x steps is the time of one real region")
     ap.add_argument("--workload", default="embed", choices=["embed", "pool", "train", "varlen"])
+    ap.add_argument("--train-lengths", default="equal", choices=["equal", "varied"],
+                    help="--workload train: `varied` = a minibatch of utterances of different lengths (a list), T uniform in [2T/3, 4T/3]")
     ap.add_argument("--utterances", type=int, default=1024, help="varlen: utterances per rank and step")
     ap.add_argument("--packing", default="ragged", choices=["ragged", "bucket"],
                     help="varlen: ragged = utterances stacked along time, borders from tables (ragged.py); bucket = "
@@ -654,11 +659,23 @@ def main():
             labels = torch.from_numpy(rs.randint(0, params.num_spkrs, size=(B,))).to(dev)
             trainer = DataParallelTrainer(net, lr=1e-4, weight_decay=1e-3, autocast_dtype=(None if compute_dtype == torch.float32 else torch.bfloat16))
 
+            xs = x
+            if args.train_lengths == "varied":
+                # north_star: minibatches of VARIABLE-LENGTH utterances — T uniform in [2T/3, 4T/3] (mean T: the dense batch's frame
+                # count), handed to the trainer as a list: one set of launches with border tables
+                lens = rs.randint(2 * T // 3, 4 * T // 3 + 1, size=B)
+                xs = [torch.from_numpy(rs.standard_normal((int(n), 80)).astype(np.float32)).to(dev) for n in lens]
+
             def step(i):
-                return trainer.train_step(x, labels, step=i)
+                return trainer.train_step(xs, labels, step=i)
             config = {"workload": "training step: forward + AM-softmax/CE + backward + Adam, input [%d,%d,80] per GPU, "
                                   "5994 speakers (BASELINE config 3/4)" % (B, T),
                       "global_batch": B * world, "frames": T, "parallelism": "dp%d (RCCL all-reduce of flat fp32 gradients)" % world}
+            if args.train_lengths == "varied":
+                config["workload"] = ("training step on a VARIABLE-LENGTH minibatch: %d utterances per GPU, T uniform in [%d,%d] (%d frames, "
+                                      "%d distinct lengths), each processed at its own length in one set of launches; forward + AM-softmax/CE "
+                                      "+ backward + Adam, 5994 speakers (BASELINE.json north_star)"
+                                      % (B, 2 * T // 3, 4 * T // 3, int(lens.sum()), len(set(lens.tolist()))))
 
     def run_steps(first, count):
         for i in range(count):

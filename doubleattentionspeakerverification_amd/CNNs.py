@@ -267,6 +267,55 @@ class _VGG(nn.Module):
             rh = ry
         return h
 
+    def _packed_ragged_training_ok(self, fdim):
+        """The packed training chain over a RAGGED batch (utterances stacked along time, border tables): exact channel counts, every
+        convolution's input a multiple of 128 channels, conv11 writing the packed form."""
+        if not (self.packed_training and self.ragged_training_ok(fdim)):
+            return False
+        cp = self.conv11.out_channels
+        if not (cp % 128 == 0 and (cp & (cp - 1)) == 0 and cp <= 1024):
+            return False
+        return all(getattr(self, "conv%d%d" % (blk, j)).in_channels % 128 == 0
+                   for blk in range(1, self.n_blocks + 1) for j in (1, 2) if (blk, j) != (1, 1))
+
+    def _forward_map_packed_ragged_train(self, x, tables):
+        """forward_map(x, tables) on packed activations: conv11 -> PACKED -> conv12 -> fp32 -> pool (+ arg-max bytes) -> PACKED -> convX1 ->
+        PACKED -> convX2 -> fp32 -> pool -> ... -> fp32 map.  Border tables in every launch; the pools stay their own launches (a tile of
+        whole row pairs does not exist across utterance borders), so convX2's output is the one fp32 activation per block.  Backward: the
+        pool writes the scattered gradient packed, convX2's data gradient reads it and the packed mask, every weight gradient copies
+        its packed x (convX2's: g too) — on the stacked image minus the cross-border products, as in the fp32 wiring."""
+        spans, pools, borders = tables
+        dev = x.device
+        x = x.contiguous()
+        r = iter(_hipconv.new_ranges(dev, 2 + 3 * self.n_blocks))
+        rx = next(r)
+        _lib = _hipconv._lib
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       "dasv_range_absmax_f32")
+        rh = next(r)
+        h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, span=spans[0], pack=True,
+                                                   x_rec=rx)
+        for blk in range(1, self.n_blocks + 1):
+            n1, n2 = "conv%d1" % blk, "conv%d2" % blk
+            c1, c2 = getattr(self, n1), getattr(self, n2)
+            sp, bd = spans[blk - 1], borders[blk - 1]
+            l1, l2 = {}, {}
+            if blk > 1:
+                ry = next(r)
+                h = _hipconv.conv3x3_bias_relu(h, c1.weight, c1.bias, self._pk(n1, dev), "split8", grad_premasked=True, link_in=l1,
+                                               x_rec=rh, y_rec=ry, span=sp, borders=bd, x_packed=True, y_packed=True)
+                rh = ry
+            ry = next(r)
+            h = _hipconv.conv3x3_bias_relu(h, c2.weight, c2.bias, self._pk(n2, dev), "split8", grad_premasked=True, mask_input_grad=True,
+                                           link_in=l2, link_out=None if blk == 1 else l1, x_rec=rh, y_rec=ry, span=sp, borders=bd,
+                                           x_packed=True, y_packed=False, grad_packed=True)
+            rh, ry = ry, next(r)
+            h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=True, link_out=l2, x_rec=rh, y_rec=ry, pool_src=pools[blk - 1],
+                                                  pack_out=blk < self.n_blocks, pack_grad=True)
+            rh = ry
+        return h
+
     def _forward_map_f16(self, x):
         """The same chain with HALF-PRECISION tensors between the layers (fp16-operand mode, inference): conv11 -> f16 -> conv12 ->
         f16 -> pool -> f16 -> ... -> convN2 -> f16 -> last pool -> fp32 map.  Every tensor holds v * 2^E, E from its range record
@@ -339,6 +388,7 @@ class _VGG(nn.Module):
             if not (hip and grad and B == 1 and self.ragged_training_ok(Fdim)):
                 raise RuntimeError("ragged training batches need the split8 mode on the GPU, gradients enabled and exact channel counts")
             spans, pools, borders = tables
+            packed_ragged = self._packed_ragged_training_ok(Fdim) and not paddedInputTensor.requires_grad
         if hip and grad and any(q.requires_grad for q in self.parameters()):
             # a pass that an optimizer step may follow: torch's FUSED optimizers update the parameters without moving their version
             # counters (the packed planes' cache key), so no packed copy made before this pass may be reused after it — neither by
@@ -349,6 +399,8 @@ class _VGG(nn.Module):
         if (hip and grad and tables is None and self.packed_training and self._mode() == "split8" and not paddedInputTensor.requires_grad
                 and self._packed_training_ok(Fdim, B, T)):
             return self._forward_map_packed_train(paddedInputTensor)
+        if tables is not None and packed_ragged:
+            return self._forward_map_packed_ragged_train(paddedInputTensor, tables)
         if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
                 and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_f16(paddedInputTensor)

@@ -223,7 +223,17 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
             raise RuntimeError("ragged batches in training run in the split8 mode (one stacked image, maps up to 80 columns)")
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
-            if mask is not None:
+            if mask is not None and mask_packed:
+                rows = lib.dasv_conv3x3_colsum_rows(3, 1, H, W, 1) if colsum is not None else 0
+                part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
+                rc = lib.dasv_conv3x3_masked_ragged_x8p_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                             mask.data_ptr(), y.data_ptr(), None if y_rec is None else y_rec.data_ptr(),
+                                                             None if part is None else part.data_ptr(), span.data_ptr(), H, W, cin, cout, stream)
+                if part is not None and rc == 0:
+                    colsum["gb"] = _sum_rows(part)
+            elif mask is not None:
+                if x_packed:
+                    raise RuntimeError("a packed gradient operand belongs to the packed training chain (packed mask)")
                 rows = lib.dasv_conv3x3_colsum_rows(3, 1, H, W, 1) if colsum is not None else 0
                 part = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if rows > 0 else None
                 rc = lib.dasv_conv3x3_masked_ragged_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(),
@@ -232,16 +242,16 @@ def _launch(x, hi, lo, bias, cout, mode, relu=1, mask=None, colsum=None, x_rec=N
                 if part is not None and rc == 0:
                     colsum["gb"] = _sum_rows(part)
             else:
-                nws = lib.dasv_conv3x3_workspace_bytes(1, H, W, cin, cout)
+                nws = 0 if y_packed else lib.dasv_conv3x3_workspace_bytes(1, H, W, cin, cout)
                 ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-                rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(x.data_ptr(), 0, x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
-                                                               None if bias is None else bias.data_ptr(), y.data_ptr(), 0,
+                rc = lib.dasv_conv3x3_bias_relu_ragged_x8_nhwc(x.data_ptr(), int(x_packed), x_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                                                               None if bias is None else bias.data_ptr(), y.data_ptr(), int(y_packed),
                                                                None if y_rec is None else y_rec.data_ptr(), span.data_ptr(),
                                                                None if ws is None else ws.data_ptr(), nws, H, W, cin, cout, relu, stream)
         _lib.check(rc, "dasv_conv3x3_*_ragged_x8_nhwc")
         return y
-    if (x_packed or y_packed or mask_packed) and (mode != "split8" or span is not None):
-        raise RuntimeError("packed activation tensors belong to the split8 mode on dense batches")
+    if (x_packed or y_packed or mask_packed) and mode != "split8":
+        raise RuntimeError("packed activation tensors belong to the split8 mode")
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if x_packed and mask is not None and not mask_packed:
@@ -308,17 +318,18 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
     utterances 1 ... n-1.  The launch on the stacked image also multiplies across every border — g of an utterance's first row with x of
     the previous utterance's last row (taps ky = 0) and g of a last row with x of the next first row (ky = 2); exactly those products
     are computed a second time from 2-row images {last row | first row} and subtracted.
-    x_packed (split8, dense): x is a PACKED activation tensor and x_rec the record its producer filled — the kernel's producer waves
+    x_packed (split8): x is a PACKED activation tensor and x_rec the record its producer filled — the kernel's producer waves
     then copy instead of converting (dasv_conv3x3_wgrad_x8p_nhwc); g_packed (with x_packed): g is packed too (the pool's backward
     wrote it that way), g_rec its record."""
-    if x_packed and (mode != "split8" or x_rec is None or borders is not None):
-        raise RuntimeError("a packed x operand: split8 mode, dense batch, with the record its producer filled")
+    if x_packed and (mode != "split8" or x_rec is None):
+        raise RuntimeError("a packed x operand: split8 mode, with the record its producer filled")
     if g_packed and not (x_packed and g_rec is not None):
         raise RuntimeError("a packed g operand: with a packed x, and the record its producer filled")
     if borders is not None and borders.numel() > 0:
         if x.shape[0] != 1:
             raise RuntimeError("a ragged batch is one stacked image")
-        tall = conv3x3_wgrad(x, g, mode, x_rec, g_rec)
+        tall = conv3x3_wgrad(x, g, mode, x_rec, g_rec, x_packed=x_packed, g_packed=g_packed)
+        # (packed operands: whole pixel rows are gathered, so their slabs stay intact, and zero bits are a packed zero)
         x3, g3 = x.permute(0, 2, 3, 1)[0], g.permute(0, 2, 3, 1)[0]              # [rows, W, C] views of the channels_last memory
         xl, xf, gl, gf = x3[borders - 1], x3[borders], g3[borders - 1], g3[borders]
         zx, zg = torch.zeros_like(xl), torch.zeros_like(gl)
@@ -327,7 +338,7 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
         if mode == "split8":           # the same scales as the stacked launch (the records bound these rows too)
             x_rec = range_of(x) if x_rec is None else x_rec
             g_rec = range_of(g) if g_rec is None else g_rec
-        return tall - conv3x3_wgrad(xb, gb, mode, x_rec, g_rec)
+        return tall - conv3x3_wgrad(xb, gb, mode, x_rec, g_rec, x_packed=x_packed, g_packed=g_packed)
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = g.shape[1]
@@ -363,7 +374,7 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
 class _ConvReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span=None, borders=None,
-                fresh=False, x_packed=False, y_packed=False):
+                fresh=False, x_packed=False, y_packed=False, g_packed=False):
         # x carries cin_x >= Cin channels (a multiple of 64; the surplus is zero) and y gets padded_channels(Cout): the layer runs
         # as its zero-padded form (see `supported`)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -376,7 +387,9 @@ class _ConvReLUFn(torch.autograd.Function):
             raise RuntimeError("a packed output's ReLU mask is applied by its consumer (grad_premasked)")
         y = _launch(x, hi, lo, bias_k, cout_p, mode, x_rec=x_rec, y_rec=y_rec, span=span, x_packed=x_packed, y_packed=y_packed)
         ctx.span, ctx.borders = span, borders           # ragged batch (one stacked image): border tables of this level
-        ctx.x_packed = x_packed
+        if g_packed and not grad_premasked:
+            raise RuntimeError("a packed incoming gradient comes pre-masked from the pool's backward")
+        ctx.x_packed, ctx.g_packed = x_packed, g_packed
         ctx.save_for_backward(x, weight, y)
         ctx.x_rec = x_rec           # (split8) the weight gradient scales x by the same record
         ctx.has_bias = bias is not None
@@ -392,7 +405,7 @@ class _ConvReLUFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         # ReLU backward in one pass (g = gy where y > 0 else 0) — unless the consumer of y already applied it
         g = gy if ctx.grad_premasked else torch.ops.aten.threshold_backward(gy, y, 0.0)
-        return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1]) + (None,) * 13
+        return _conv_backward(ctx, x, weight, g, _rec_of(gy), y.shape[1], g_packed=ctx.g_packed) + (None,) * 14
 
 
 def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p, g_packed=False):
@@ -637,7 +650,8 @@ def conv3x3_bias_relu_pool(x, weight, bias, packed=None, mask_input_grad=False, 
 
 
 def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked=False, mask_input_grad=False,
-                      link_in=None, link_out=None, x_rec=None, y_rec=None, span=None, borders=None, x_packed=False, y_packed=False):
+                      link_in=None, link_out=None, x_rec=None, y_rec=None, span=None, borders=None, x_packed=False, y_packed=False,
+                      grad_packed=False):
     """relu(conv2d(x, weight, bias, stride 1, padding 1)) for x [B,Cin,H,W] fp32 on the GPU; returns channels_last.
 
     Two backward fusions a caller that knows the graph may switch on (the VGG front-end does; results are identical):
@@ -656,7 +670,8 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     x_packed / y_packed (training on PACKED activations, split8, dense batches, exact channel counts with Cin % 128 == 0): x and / or
     the result are packed activation tensors (conv3x3_x8) with their records in x_rec / y_rec — the weight gradient then reads x
     without converting it and the data-gradient kernel takes the ReLU mask from x's fp16 plane; a packed result requires
-    grad_premasked (its consumer applies the mask).
+    grad_premasked (its consumer applies the mask).  grad_packed: the gradient that will arrive at the result is a packed tensor (the
+    consumer is maxpool2x2_ceil_autograd(..., pack_grad=True)).
     Channel counts that are not multiples of (64, 128): x may carry more channels than the layer has inputs (zeros), and the
     result carries padded_channels(Cout) channels, the surplus identically zero (see `supported`); slice when needed."""
     if not x.is_cuda:
@@ -682,7 +697,7 @@ def conv3x3_bias_relu(x, weight, bias, packed=None, mode="split", grad_premasked
     # grad mode is off inside an autograd Function's forward and ctx.needs_input_grad ignores torch.no_grad())
     fresh = torch.is_grad_enabled() and weight.requires_grad
     return _ConvReLUFn.apply(x, weight, b, packed, mode, grad_premasked, mask_input_grad, link_in, link_out, x_rec, y_rec, span, borders, fresh,
-                             x_packed, y_packed)
+                             x_packed, y_packed, grad_packed)
 
 
 def conv3x3_c1_bias_relu(x, weight, bias, pack=False, x_rec=None, y_rec=None):
@@ -879,8 +894,10 @@ class _MaxPoolFn(torch.autograd.Function):
     bytes and the incoming gradient only — the full-resolution map is not saved and not read again."""
 
     @staticmethod
-    def forward(ctx, x, relu_input, link_out, x_rec, y_rec, pool_src=None):
+    def forward(ctx, x, relu_input, link_out, x_rec, y_rec, pool_src=None, pack_out=False, pack_grad=False):
         lib = _lib.load()
+        if (pack_out or pack_grad) and (pool_src is None or x_rec is None or y_rec is None or not relu_input):
+            raise RuntimeError("packed pool output / gradient: the ragged packed training chain (records, ReLU input)")
         if not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         B, C, H, W = x.shape
@@ -897,10 +914,11 @@ class _MaxPoolFn(torch.autograd.Function):
             else:
                 if B != 1:
                     raise RuntimeError("a ragged batch is one stacked image")
-                rc = lib.dasv_maxpool2x2_ceil_idx_ragged_nhwc(x.data_ptr(), xr, y.data_ptr(), yr, idx.data_ptr(), pool_src.data_ptr(),
-                                                              H, Ho, W, C, st)
+                fn = lib.dasv_maxpool2x2_ceil_idx_ragged_x8_nhwc if pack_out else lib.dasv_maxpool2x2_ceil_idx_ragged_nhwc
+                rc = fn(x.data_ptr(), xr, y.data_ptr(), yr, idx.data_ptr(), pool_src.data_ptr(), H, Ho, W, C, st)
         _lib.check(rc, "dasv_maxpool2x2_ceil_idx_nhwc")
         ctx.save_for_backward(idx)
+        ctx.pack_grad = pack_grad
         ctx.pool_src = pool_src
         ctx.xshape = (B, C, H, W)
         ctx.relu_input = relu_input
@@ -922,7 +940,16 @@ class _MaxPoolFn(torch.autograd.Function):
             else:
                 rows = lib.dasv_maxpool2x2_bwd_colsum_rows_ragged(int(ctx.pool_src.shape[0]), W, C) if want_sum else 0
             part = torch.empty((rows, C), dtype=torch.float32, device=gy.device) if rows > 0 else None
-            if ctx.pool_src is None:
+            rec = _rec_of(gy)
+            if ctx.pack_grad:         # the scattered gradient PACKED, scaled by the exponent of gy's maximum (its own maximum)
+                if rec is None:
+                    rec = range_of(gy)
+                grec = new_ranges(gy.device)[0]
+                rc = lib.dasv_maxpool2x2_ceil_bwd_idx_ragged_x8_nhwc(idx.data_ptr(), gy.data_ptr(), rec.data_ptr(), gx.data_ptr(), grec.data_ptr(),
+                                                                     None if part is None else part.data_ptr(), int(bool(ctx.relu_input)),
+                                                                     ctx.pool_src.data_ptr(), H, int(ctx.pool_src.shape[0]), W, C, stream)
+                rec = grec
+            elif ctx.pool_src is None:
                 rc = lib.dasv_maxpool2x2_ceil_bwd_idx_nhwc(idx.data_ptr(), gy.data_ptr(), gx.data_ptr(), None if part is None else part.data_ptr(),
                                                            int(bool(ctx.relu_input)), B, H, W, C, stream)
             else:
@@ -932,19 +959,20 @@ class _MaxPoolFn(torch.autograd.Function):
             if part is not None and rc == 0:
                 ctx.link_out["gb"] = _sum_rows(part)
         _lib.check(rc, "dasv_maxpool2x2_ceil_bwd_idx_nhwc")
-        rec = _rec_of(gy)
         if rec is not None:      # the scattered gradient's range record is its source's (a bound: max |gx| <= max |gy|)
             _attach_rec(gx, rec)
-        return gx, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None
 
 
-def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None, x_rec=None, y_rec=None, pool_src=None):
+def maxpool2x2_ceil_autograd(x, relu_input=False, link_out=None, x_rec=None, y_rec=None, pool_src=None, pack_out=False, pack_grad=False):
     """Differentiable F.max_pool2d(x, 2, stride=2, ceil_mode=True) for channels_last fp32 GPU tensors.
 
     relu_input=True: x is the output of a conv3x3_bias_relu(..., grad_premasked=True) call and nothing else consumes it —
     the backward then also passes the gradient through that ReLU (one fused pass instead of two), and leaves that conv's
-    bias gradient in `link_out["gb"]` (see conv3x3_bias_relu)."""
-    return _MaxPoolFn.apply(x, relu_input, link_out, x_rec, y_rec, pool_src)
+    bias gradient in `link_out["gb"]` (see conv3x3_bias_relu).
+    pack_out / pack_grad (ragged packed training chain, pool_src given): the pooled map / the gradient sent back to x are PACKED
+    tensors (conv3x3_x8) — x itself stays fp32."""
+    return _MaxPoolFn.apply(x, relu_input, link_out, x_rec, y_rec, pool_src, pack_out, pack_grad)
 
 
 class _Conv11ReLUFn(torch.autograd.Function):
@@ -952,8 +980,8 @@ class _Conv11ReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, y_rec, grad_premasked=False, span=None, pack=False, x_rec=None):
-        if pack and (span is not None or not grad_premasked):
-            raise RuntimeError("a packed first-layer output: dense batches, ReLU mask applied by the consumer")
+        if pack and not grad_premasked:
+            raise RuntimeError("a packed first-layer output: the ReLU mask is applied by the consumer")
         if span is None:
             y = conv3x3_c1_bias_relu(x, weight, bias, pack=pack, x_rec=x_rec, y_rec=y_rec)
         else:      # ragged batch: x [1, rows, W], utterances stacked along the rows, borders from `span`
@@ -964,10 +992,18 @@ class _Conv11ReLUFn(torch.autograd.Function):
                 raise RuntimeError("a ragged batch is one stacked image")
             y = torch.empty((1, weight.shape[0], H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
             with torch.cuda.device(x.device):
-                rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
-                                                               None if bias is None else bias.detach().data_ptr(), y.data_ptr(),
-                                                               None if y_rec is None else y_rec.data_ptr(), span.data_ptr(), H, W,
-                                                               weight.shape[0], 1, torch.cuda.current_stream(x.device).cuda_stream)
+                if pack:
+                    if x_rec is None:
+                        x_rec = range_of(x)
+                    rc = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(x.data_ptr(), x_rec.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                                      None if bias is None else bias.detach().data_ptr(), y.data_ptr(),
+                                                                      y_rec.data_ptr(), span.data_ptr(), H, W, weight.shape[0], 1,
+                                                                      torch.cuda.current_stream(x.device).cuda_stream)
+                else:
+                    rc = lib.dasv_conv3x3_c1_bias_relu_ragged_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                                   None if bias is None else bias.detach().data_ptr(), y.data_ptr(),
+                                                                   None if y_rec is None else y_rec.data_ptr(), span.data_ptr(), H, W,
+                                                                   weight.shape[0], 1, torch.cuda.current_stream(x.device).cuda_stream)
             _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_nhwc")
         ctx.span = span
         ctx.save_for_backward(x.contiguous(), y)

@@ -2086,6 +2086,16 @@ int dasv_conv3x3_masked_x8_nhwc(const float* x, const uint32_t* x_range, const v
                           Cin, Cout, 0, stream, nullptr, 0, 0, x_range, y_range);
 }
 
+int dasv_conv3x3_masked_ragged_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                        const void* mask_packed, float* y, uint32_t* y_range, float* colsum_partial, const int* row_span,
+                                        int rows, int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask_packed == nullptr || row_span == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, static_cast<const float*>(mask_packed),
+                          colsum_partial, y, nullptr, 0, 1, rows, W, Cin, Cout, 0, stream, row_span, x_packed ? 1 : 0, 0, x_range, y_range, 0, 0,
+                          nullptr, 1);
+}
+
 int dasv_conv3x3_masked_c1_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3, const void* mask,
                                     int mask_packed, const float* mel, float* c1_partial, int B, int H, int W, int Cin, int Cout,
                                     dasv_stream_t stream) {

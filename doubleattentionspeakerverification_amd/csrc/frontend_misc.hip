@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
                                                                   long long nvec, int relu_mask, float* __restrict__ colsum,
                                                                   const uint8_t* __restrict__ idx, const int* __restrict__ pool_src,
                                                                   const uint32_t* __restrict__ gy_rec, uint32_t* __restrict__ gx_rec) {
-    // gy_rec / gx_rec (both or neither; dense batches): gx is written as a PACKED tensor (dasv_common.hpp, store_x8) scaled by the
+    // gy_rec / gx_rec (both or neither): gx is written as a PACKED tensor (dasv_common.hpp, store_x8) scaled by the
     // exponent of gy's recorded maximum — the scattered gradient has the same maximum — and gx_rec receives {that maximum, the exponent}:
     // the data-gradient and weight-gradient launches that consume gx then copy its pieces instead of converting fp32 values
     // pool_src (ragged batch: B == 1, H = total input rows, Ho = total output rows): {first input row, has-second-row} per output row
@@ -700,7 +700,7 @@ static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B,
                               float* colsum, dasv_stream_t stream, const uint8_t* idx = nullptr, const int* pool_src = nullptr,
                               int rows_out = 0, const uint32_t* gy_rec = nullptr, uint32_t* gx_rec = nullptr) {
     if ((gy_rec == nullptr) != (gx_rec == nullptr)) return DASV_E_NULL;
-    if (gx_rec != nullptr && (C % 64 != 0 || pool_src != nullptr)) return DASV_E_SHAPE;
+    if (gx_rec != nullptr && C % 64 != 0) return DASV_E_SHAPE;
     if (colsum != nullptr && (C / 4 > 256 || 256 % (C / 4) != 0)) return DASV_E_SHAPE;
     if ((x == nullptr && idx == nullptr) || gy == nullptr || gx == nullptr) return DASV_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
@@ -741,6 +741,22 @@ int dasv_maxpool2x2_ceil_bwd_idx_x8_nhwc(const uint8_t* idx, const float* gy, co
     if (idx == nullptr || gy_range == nullptr || gx_range == nullptr) return DASV_E_NULL;
     return maxpool_bwd_launch(nullptr, gy, static_cast<float*>(gx_packed), B, H, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx, nullptr, 0,
                               gy_range, gx_range);
+}
+
+/* the packed training chain over a ragged batch: the pool writes its output PACKED next to the arg-max bytes, its backward the
+ * scattered gradient */
+int dasv_maxpool2x2_ceil_idx_ragged_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, uint8_t* idx,
+                                            const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr || pool_src == nullptr) return DASV_E_NULL;
+    return pool_launch(x, static_cast<float*>(y_packed), pool_src, 1, rows_in, rows_out, W, C, 1, x_range, y_range, stream, 0, idx);
+}
+
+int dasv_maxpool2x2_ceil_bwd_idx_ragged_x8_nhwc(const uint8_t* idx, const float* gy, const uint32_t* gy_range, void* gx_packed,
+                                                uint32_t* gx_range, float* colsum_partial, int relu_mask, const int* pool_src, int rows_in,
+                                                int rows_out, int W, int C, dasv_stream_t stream) {
+    if (idx == nullptr || pool_src == nullptr || gy_range == nullptr || gx_range == nullptr) return DASV_E_NULL;
+    return maxpool_bwd_launch(nullptr, gy, static_cast<float*>(gx_packed), 1, rows_in, W, C, relu_mask ? 1 : 0, colsum_partial, stream, idx,
+                              pool_src, rows_out, gy_range, gx_range);
 }
 
 /* the training pool and its backward over a ragged batch (pool_src as in dasv_maxpool2x2_ceil_ragged_nhwc): utterances of different

@@ -296,6 +296,16 @@ int dasv_maxpool2x2_bwd_colsum_rows_ragged(int rows_out, int W, int C);
 int dasv_conv3x3_masked_ragged_x8_nhwc(const float* x, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
                                        const float* mask, float* y, uint32_t* y_range, float* colsum_partial, const int* row_span,
                                        int rows, int W, int Cin, int Cout, dasv_stream_t stream);
+/* ... and on PACKED activations (the packed training chain, below, over a ragged batch): the pool's packed output beside the arg-max
+ * bytes, its packed scattered gradient, and the masked data gradient with packed x / packed mask. */
+int dasv_maxpool2x2_ceil_idx_ragged_x8_nhwc(const float* x, const uint32_t* x_range, void* y_packed, uint32_t* y_range, uint8_t* idx,
+                                            const int* pool_src, int rows_in, int rows_out, int W, int C, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_bwd_idx_ragged_x8_nhwc(const uint8_t* idx, const float* gy, const uint32_t* gy_range, void* gx_packed,
+                                                uint32_t* gx_range, float* colsum_partial, int relu_mask, const int* pool_src, int rows_in,
+                                                int rows_out, int W, int C, dasv_stream_t stream);
+int dasv_conv3x3_masked_ragged_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                        const void* mask_packed, float* y, uint32_t* y_range, float* colsum_partial, const int* row_span,
+                                        int rows, int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float* gy, float* gw, float* gb, void* workspace,
                                     size_t workspace_bytes, const int* row_span, int rows, int W, int Cout, dasv_stream_t stream);
 /* Border tables of a ragged batch (utterances of different lengths stacked along time: what the reference does one utterance per

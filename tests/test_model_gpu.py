@@ -204,13 +204,18 @@ def test_variable_length_minibatch_train_step_vs_float64(monkeypatch):
     assert abs(float(loss2) - float(loss)) < 1e-5 * abs(float(loss)) and float((net.fc1.weight - before).abs().max()) > 0
 
 
-def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buckets(monkeypatch):
+@pytest.mark.parametrize("packed", [True, False])
+def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buckets(packed, monkeypatch):
     """The same semantics as the test above — every utterance of a training minibatch at its own length, one dense tail — but as
     ONE set of launches: the utterances stacked along time, the front-end's forward, data-gradient, weight-gradient, pool and conv11
     kernels taking the utterance borders from tables (ragged.utterance_vectors_ragged_train; the weight gradient subtracts the
     cross-border products).  VGG4L at the reference's default width (the stacked path needs channel counts the kernels take without
     padding).  (1) Loss and every gradient element against the float64 oracle on the same list under the decisions the HIP forward
-    took, flips counted; (2) against the one-dense-pass-per-length path of the same model: same loss, gradients to 4e-5."""
+    took, flips counted; (2) against the one-dense-pass-per-length path of the same model: same loss, gradients to 4e-5.
+    packed: the stacked batch on PACKED activations (CNNs._forward_map_packed_ragged_train: packed tensors between the layers, the pool's
+    backward writing a packed gradient, packed operands in the weight gradients and the packed mask in the data gradients — the shipped
+    wiring) or on fp32 activations; (2) holds element by element only between forwards of the same arithmetic (the fp32 wiring and the
+    per-length passes), with the packed chain the loss."""
     from doubleattentionspeakerverification_amd.model import SpeakerClassifier
     from _decisions import DecisionCapture
     p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
@@ -223,11 +228,16 @@ def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buck
     keep = torch.rand(len(lens), p.heads_number) > 0.3
     keep[:, 1] = True
     assert net.ragged_training == "stacked" and net.front_end.ragged_training_ok()
+    net.front_end.packed_training = packed
+    took = []
+    inner = net.front_end._forward_map_packed_ragged_train
+    monkeypatch.setattr(net.front_end, "_forward_map_packed_ragged_train", lambda *a: (took.append(1), inner(*a))[1])
     monkeypatch.setattr(net.poolingLayer.headsAttention, "draw_head_keep", lambda batch, heads, device: keep.to(device))
     with DecisionCapture(monkeypatch, net.front_end) as cap:
         loss, _ = net.forward_loss([u.to(DEV) for u in utts], lab.to(DEV), 0)
         loss.backward()
         assert net.last_ragged_buckets is None and len(cap.events) == 12          # ONE pass over the stacked batch
+        assert len(took) == (1 if packed else 0)
         decs = cap.decisions_stacked(lens)
     grads = {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
@@ -253,7 +263,7 @@ def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buck
     loss_b.backward()
     assert net.last_ragged_buckets == buckets and abs(float(loss_b.detach()) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
     for n, q in net.named_parameters():
-        if q.grad is not None:
+        if q.grad is not None and not packed:
             a, b = grads[n], q.grad
             assert float((a - b).abs().max()) <= 4e-5 * max(1.0, float(b.abs().max())) + (4e-3 if b.dim() == 1 else 0.0), n
 

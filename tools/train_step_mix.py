@@ -5,7 +5,7 @@ usage: train_step_mix.py <kernel_trace.csv> [out.md]"""
 import collections, csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-ends = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+ends = [i for i, n in enumerate(names) if "multi_tensor_apply" in n or "adam_step_kernel" in n]
 groups = []
 for i in ends:
     if groups and i - groups[-1][-1] <= 3: groups[-1].append(i)

@@ -3,7 +3,7 @@
 in launch order: start offset, duration, grid, name.  usage: train_step_seq.py <kernel_trace.csv> [out.txt]"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"] or "adam_step_kernel" in r["Kernel_Name"]]
 groups = []
 for i in ends:
     if groups and i - groups[-1][-1] <= 3: groups[-1].append(i)
