@@ -1339,7 +1339,10 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     // channels] rows of 528 bytes (the 16-byte pad makes the b128 writes of 8 pixels hit 32 distinct banks) — and is written out
     // as whole 512-byte pixel rows, two per wave-instruction.
     if constexpr (PIPELINED) {
-        {
+        // (fp16 operands: no masked launch exists in the product — its gradients run on the bf16 / split kernels — so those kernels keep
+        // the plain write-out only and hand a masked call to the direct epilogue below; same-process A/B of the two builds: the masked
+        // write-out's code in the fp16 kernels cost the fp16 inference chain 1.4 %)
+        if (PREC != PREC_F16 || (p.mask == nullptr && p.colsum == nullptr)) {
             constexpr int OP = 528;
             DASV_STAMP(60);
             __syncthreads();                     // every wave is done with the window and the tiles
@@ -1501,6 +1504,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             // data-gradient launches (a ReLU's backward fused: outputs zeroed where mask <= 0; per-channel sums of the stored rows =
             // the bias gradient of the layer below): the mask is read, and the output written, in the same whole 512-byte pixel rows;
             // the mask rows of the first passes are requested before the image is read
+            if constexpr (PREC != PREC_F16) {
             static_assert(NT == 512, "16 pixel rows per pass");
             f32x4 csum = {0.f, 0.f, 0.f, 0.f};
             const bool c1f = X8 && p.c1_part != nullptr;
@@ -1600,6 +1604,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             }
             DASV_STAMP(63);
             return;
+            }
         }
     }
     // epilogue: D[row = channel][col = pixel]: lane holds channels n .. n+3 of pixel m
