@@ -3,8 +3,9 @@
  * (oracle/dmha_oracle.c, linked in as the checker).  Built and run by tests/test_cabi_native_gpu.py.
  * Shapes: the reference's `DoubleMHA(512, 8)` on [B,T,512] (BASELINE config 2 at a size the scalar checker finishes fast),
  * then one conv3x3+bias+ReLU layer against a naive convolution, then the DEFAULT path of the front-end — range record ->
- * split8 convolution -> max-pool, and convolution + pool as one launch — and the AM-softmax + cross-entropy head, forward and
- * backward, each against a plain-C double-precision restatement written right here. */
+ * split8 convolution -> max-pool, and convolution + pool as one launch — the AM-softmax + cross-entropy head, forward and
+ * backward, and the TRAINING entry points of the default arithmetic (conv + pool with arg-max bytes, pool backward, masked data
+ * gradient, weight gradient, column sums, flat Adam), each against a plain-C double-precision restatement written right here. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdint.h>
@@ -238,6 +239,151 @@ int main(void) {
         printf("amsoftmax: loss %.7g (ref %.7g), max|err| costh %.3g, gx %.3g of %.3g, gW %.3g of %.3g\n", loss_h, lossr, e_cos, e_gx, s_gx,
                e_gW, s_gW);
         ok = ok && fabs(loss_h - lossr) < 2e-5 * fabs(lossr) && e_cos < 2e-6 && e_gx < 1e-4 * s_gx && e_gW < 1e-4 * s_gW;
+    }
+    /* ---- the TRAINING entry points of the default arithmetic (train.py:215-224 through CNNs.py:72-74): conv + ReLU + pool in one
+     * launch with arg-max bytes, the pool's backward from those bytes, the masked data gradient with planes packed straight from the
+     * forward weight, the weight gradient, the column-sum reduction and the flat Adam step — each against plain C in double ---- */
+    {
+        const int tB = 2, tH = 6, tW = 5, tc = 64, tn = 128, qH = 3, qW = 3;     /* layer A: conv + pool, pool backward */
+        const size_t nX = (size_t)tB * tH * tW * tc, nY = (size_t)tB * tH * tW * tn, nW = (size_t)tn * tc * 9, nP = (size_t)tB * qH * qW * tn;
+        float *tx = malloc(nX * 4), *tw = malloc(nW * 4), *tb = malloc((size_t)tn * 4), *tgy = malloc(nP * 4);
+        for (size_t i = 0; i < nX; ++i) { tx[i] = frand(&seed); if (tx[i] < 0) tx[i] = 0; }          /* a ReLU output */
+        for (size_t i = 0; i < nW; ++i) tw[i] = 0.05f * frand(&seed);
+        for (int i = 0; i < tn; ++i) tb[i] = 0.1f * frand(&seed);
+        for (size_t i = 0; i < nP; ++i) tgy[i] = 1e-3f * frand(&seed);
+        /* forward in double: z (pre-ReLU map), then per window the first maximum in row-major order */
+        double* z = malloc(nY * sizeof(double));
+        for (int b = 0; b < tB; ++b) for (int h = 0; h < tH; ++h) for (int w = 0; w < tW; ++w) for (int n = 0; n < tn; ++n) {
+            double acc = tb[n];
+            for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+                const int hh = h + ky - 1, ww = w + kx - 1;
+                if (hh < 0 || hh >= tH || ww < 0 || ww >= tW) continue;
+                const float* xp = tx + (((size_t)b * tH + hh) * tW + ww) * tc;
+                for (int c = 0; c < tc; ++c) acc += (double)xp[c] * tw[((size_t)n * tc + c) * 9 + ky * 3 + kx];
+            }
+            z[(((size_t)b * tH + h) * tW + w) * tn + n] = acc < 0 ? 0 : acc;
+        }
+        float *dtx, *dtw, *dtb, *dty, *dpool, *dgy, *dg, *dgx, *dgw, *dcol, *dcolsum;
+        uint8_t* didx;
+        uint32_t* trec;
+        void *tw16, *tw8, *dw16, *dw8, *wws;
+        const size_t wwb = dasv_conv3x3_wgrad_workspace_bytes(tB, tH, tW, 128, tn);
+        const int crow = dasv_maxpool2x2_bwd_colsum_rows(tB, tH, tW, tn);
+        CHECK(hipMalloc((void**)&dtx, nX * 4)); CHECK(hipMalloc((void**)&dtw, nW * 4)); CHECK(hipMalloc((void**)&dtb, (size_t)tn * 4));
+        CHECK(hipMalloc((void**)&dty, nY * 4)); CHECK(hipMalloc((void**)&dpool, nP * 4)); CHECK(hipMalloc((void**)&dgy, nP * 4));
+        CHECK(hipMalloc((void**)&dg, nY * 4)); CHECK(hipMalloc((void**)&dgx, 2 * nX * 4)); CHECK(hipMalloc((void**)&dgw, 2 * nW * 4));
+        CHECK(hipMalloc((void**)&dcol, (size_t)crow * tn * 4)); CHECK(hipMalloc((void**)&dcolsum, (size_t)tn * 4));
+        CHECK(hipMalloc((void**)&didx, nP)); CHECK(hipMalloc((void**)&trec, 16 * sizeof(uint32_t)));
+        CHECK(hipMalloc(&tw16, dasv_conv3x3_packed_weight_bytes_f16(tn, tc))); CHECK(hipMalloc(&tw8, dasv_conv3x3_packed_weight_bytes_x8(tn, tc)));
+        CHECK(hipMalloc(&dw16, dasv_conv3x3_packed_weight_bytes_f16(128, tn))); CHECK(hipMalloc(&dw8, dasv_conv3x3_packed_weight_bytes_x8(128, tn)));
+        CHECK(hipMalloc(&wws, wwb));
+        CHECK(hipMemcpy(dtx, tx, nX * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dtw, tw, nW * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dtb, tb, (size_t)tn * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dgy, tgy, nP * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemsetAsync(trec, 0, 16 * sizeof(uint32_t), st));
+        rc = dasv_range_absmax_f32(dtx, nX, trec, st);                                   /* record 0: x */
+        if (!rc) rc = dasv_range_absmax_f32(dgy, nP, trec + 2, st);                      /* record 1: the pooled gradient */
+        if (!rc) rc = dasv_conv3x3_pack_weights_x8(dtw, dtb, tw16, tw8, tn, tc, st);
+        if (!rc) rc = dasv_conv3x3_pool_supported(3, tB, tH, tW, tc, tn) ? 0 : DASV_E_SHAPE;
+        if (!rc) rc = dasv_conv3x3_bias_relu_pool_idx_x8_nhwc(dtx, 0, trec, tw16, tw8, dtb, dpool, 0, trec + 4, didx, tB, tH, tW, tc, tn, st);
+        if (!rc) rc = dasv_maxpool2x2_ceil_bwd_idx_nhwc(didx, dgy, dg, dcol, 1, tB, tH, tW, tn, st);      /* g = gradient at conv's pre-activation */
+        if (!rc) rc = dasv_colsum_reduce(dcol, crow, tn, dcolsum, st);                                  /* = the bias gradient */
+        /* layer B (128 -> 128; the data-gradient convolution writes 128-channel tiles): masked data gradient and weight gradient of the
+         * gradient tensor g made above, against an input xb and weights wb of their own */
+        const int bc = 128;
+        const size_t nXb = (size_t)tB * tH * tW * bc, nWb = (size_t)tn * bc * 9;
+        float *xb = malloc(nXb * 4), *wb = malloc(nWb * 4), *dxb, *dwb;
+        for (size_t i = 0; i < nXb; ++i) { xb[i] = frand(&seed); if (xb[i] < 0) xb[i] = 0; }
+        for (size_t i = 0; i < nWb; ++i) wb[i] = 0.05f * frand(&seed);
+        CHECK(hipMalloc((void**)&dxb, nXb * 4)); CHECK(hipMalloc((void**)&dwb, nWb * 4));
+        CHECK(hipMemcpy(dxb, xb, nXb * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dwb, wb, nWb * 4, hipMemcpyHostToDevice));
+        if (!rc) rc = dasv_range_absmax_f32(dxb, nXb, trec + 8, st);
+        if (!rc) rc = dasv_conv3x3_pack_weights_x8_dgrad(dwb, dw16, dw8, tn, bc, st);
+        if (!rc) rc = dasv_conv3x3_masked_x8_nhwc(dg, trec + 2, dw16, dw8, dxb, dgx, trec + 6, NULL, tB, tH, tW, tn, bc, st);
+        if (!rc) rc = dasv_conv3x3_wgrad_x8_nhwc(dxb, trec + 8, dg, trec + 2, dgw, wws, wwb, tB, tH, tW, bc, tn, st);
+        if (rc) { fprintf(stderr, "training path: %s\n", dasv_error_string(rc)); return 4; }
+        float *pool_h = malloc(nP * 4), *g_h = malloc(nY * 4), *gx_h = malloc(nXb * 4), *gw_h = malloc(nWb * 4), colsum_h[128];
+        uint8_t* idx_h = malloc(nP);
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(pool_h, dpool, nP * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(idx_h, didx, nP, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(g_h, dg, nY * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(gx_h, dgx, nXb * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(gw_h, dgw, nWb * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(colsum_h, dcolsum, (size_t)tn * 4, hipMemcpyDeviceToHost));
+        /* pooled map and arg-max bytes; a window whose two largest values agree to 1e-5 may hand on either: counted, must be rare */
+        double e_pl = 0, s_pl = 0, *gref = calloc(nY, sizeof(double)), gbr[128] = {0};
+        int near_ties = 0, bad_idx = 0;
+        for (int b = 0; b < tB; ++b) for (int h = 0; h < qH; ++h) for (int w = 0; w < qW; ++w) for (int n = 0; n < tn; ++n) {
+            double m = -1, second = -1;
+            int arg = 0;
+            for (int pos = 0; pos < 4; ++pos) {
+                const int hh = 2 * h + (pos >> 1), ww = 2 * w + (pos & 1);
+                if (hh >= tH || ww >= tW) continue;
+                const double v = z[(((size_t)b * tH + hh) * tW + ww) * tn + n];
+                if (v > m) { second = m; m = v; arg = pos; } else if (v > second) second = v;
+            }
+            const size_t o = (((size_t)b * qH + h) * qW + w) * tn + n;
+            e_pl = fmax(e_pl, fabs((double)pool_h[o] - m)); s_pl = fmax(s_pl, m);
+            const int code = idx_h[o], got_arg = code & 3, got_pos = (code & 4) != 0;
+            if (got_arg != arg || got_pos != (m > 0)) { if (m - second < 1e-4 || m < 1e-4) ++near_ties; else ++bad_idx; }
+            /* the backward follows the LAUNCH's decisions (its own bytes): g at the byte's position, if the byte says positive */
+            const int hh = 2 * h + (got_arg >> 1), ww = 2 * w + (got_arg & 1);
+            if (got_pos) { gref[(((size_t)b * tH + hh) * tW + ww) * tn + n] = tgy[o]; gbr[n] += tgy[o]; }
+        }
+        double e_g = 0, e_gb = 0, s_gb = 0, e_gx = 0, s_gx = 0, e_gw = 0, s_gw = 0;
+        for (size_t i = 0; i < nY; ++i) e_g = fmax(e_g, fabs((double)g_h[i] - gref[i]));      /* a scatter: exact */
+        for (int n = 0; n < tn; ++n) { e_gb = fmax(e_gb, fabs(colsum_h[n] - gbr[n])); s_gb = fmax(s_gb, fabs(gbr[n])); }
+        for (int b = 0; b < tB; ++b) for (int h = 0; h < tH; ++h) for (int w = 0; w < tW; ++w) for (int c = 0; c < bc; ++c) {
+            double acc = 0;                            /* gx = sum_n,ky,kx g[h - ky + 1][w - kx + 1][n] W[n][c][ky][kx], where x > 0 */
+            for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+                const int hh = h - ky + 1, ww = w - kx + 1;
+                if (hh < 0 || hh >= tH || ww < 0 || ww >= tW) continue;
+                const double* gp = gref + (((size_t)b * tH + hh) * tW + ww) * tn;
+                for (int n = 0; n < tn; ++n) acc += gp[n] * wb[((size_t)n * bc + c) * 9 + ky * 3 + kx];
+            }
+            const size_t o = (((size_t)b * tH + h) * tW + w) * bc + c;
+            if (!(xb[o] > 0)) acc = 0;
+            e_gx = fmax(e_gx, fabs((double)gx_h[o] - acc)); s_gx = fmax(s_gx, fabs(acc));
+        }
+        for (int n = 0; n < tn; ++n) for (int c = 0; c < bc; ++c) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
+            double acc = 0;                            /* gw = sum_pix g[pix][n] x[pix + tap][c] */
+            for (int b = 0; b < tB; ++b) for (int h = 0; h < tH; ++h) for (int w = 0; w < tW; ++w) {
+                const int hh = h + ky - 1, ww = w + kx - 1;
+                if (hh < 0 || hh >= tH || ww < 0 || ww >= tW) continue;
+                acc += gref[(((size_t)b * tH + h) * tW + w) * tn + n] * xb[(((size_t)b * tH + hh) * tW + ww) * bc + c];
+            }
+            const size_t o = ((size_t)n * bc + c) * 9 + ky * 3 + kx;
+            e_gw = fmax(e_gw, fabs((double)gw_h[o] - acc)); s_gw = fmax(s_gw, fabs(acc));
+        }
+        /* flat Adam (train.py:82-84, 224): three steps on 256 values, the second 64-element block frozen */
+        enum { AN = 256 };
+        float ap[AN], ag[AN], am[AN] = {0}, av[AN] = {0}, *dap, *dag, *dam, *dav;
+        double rp[AN], rm[AN] = {0}, rv[AN] = {0};
+        uint8_t act[AN / 64] = {1, 0, 1, 1}, *dact;
+        for (int i = 0; i < AN; ++i) { ap[i] = frand(&seed); rp[i] = ap[i]; }
+        CHECK(hipMalloc((void**)&dap, AN * 4)); CHECK(hipMalloc((void**)&dag, AN * 4)); CHECK(hipMalloc((void**)&dam, AN * 4));
+        CHECK(hipMalloc((void**)&dav, AN * 4)); CHECK(hipMalloc((void**)&dact, AN / 64));
+        CHECK(hipMemcpy(dap, ap, AN * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dam, am, AN * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dav, av, AN * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dact, act, AN / 64, hipMemcpyHostToDevice));
+        const double lr = 1e-2, b1 = 0.9, b2 = 0.999, eps = 1e-8, wd = 1e-3;
+        for (int step = 1; step <= 3; ++step) {
+            for (int i = 0; i < AN; ++i) ag[i] = 0.1f * frand(&seed);
+            CHECK(hipMemcpy(dag, ag, AN * 4, hipMemcpyHostToDevice));
+            rc = dasv_adam_step_f32(dap, dag, dam, dav, dact, AN, (float)lr, (float)b1, (float)b2, (float)eps, (float)wd, step, 1, st);
+            if (rc) { fprintf(stderr, "adam: %s\n", dasv_error_string(rc)); return 4; }
+            for (int i = 0; i < AN; ++i) {
+                if (!act[i / 64]) continue;
+                const double gr = ag[i] + wd * rp[i];
+                rm[i] = b1 * rm[i] + (1 - b1) * gr; rv[i] = b2 * rv[i] + (1 - b2) * gr * gr;
+                rp[i] -= lr / (1 - pow(b1, step)) * rm[i] / (sqrt(rv[i]) / sqrt(1 - pow(b2, step)) + eps);
+            }
+        }
+        CHECK(hipStreamSynchronize(st));
+        CHECK(hipMemcpy(ap, dap, AN * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ag, dag, AN * 4, hipMemcpyDeviceToHost));
+        double e_ad = 0, g_left = 0;
+        for (int i = 0; i < AN; ++i) { e_ad = fmax(e_ad, fabs(ap[i] - rp[i])); if (act[i / 64]) g_left = fmax(g_left, fabs(ag[i])); }
+        printf("training: conv+pool max|err| %.3g of %.3g, arg-max bytes: %d wrong, %d near ties of %zu; pool backward max|err| %.3g; bias gradient "
+               "%.3g of %.3g; data gradient %.3g of %.3g; weight gradient %.3g of %.3g; adam max|err| %.3g, gradient left %.3g\n",
+               e_pl, s_pl, bad_idx, near_ties, nP, e_g, e_gb, s_gb, e_gx, s_gx, e_gw, s_gw, e_ad, g_left);
+        ok = ok && e_pl < 4e-5 * s_pl && bad_idx == 0 && near_ties <= 4 && e_g == 0 && e_gb < 1e-5 * s_gb && e_gx < 5e-5 * s_gx &&
+             e_gw < 8e-5 * s_gw && e_ad < 2e-6 && g_left == 0;
     }
     puts(ok ? "CABI_NATIVE_OK" : "CABI_NATIVE_FAIL");
     return ok ? 0 : 1;
