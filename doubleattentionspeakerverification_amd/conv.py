@@ -317,7 +317,7 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
     borders (ragged batch: x / g are utterances stacked along H in one image, B == 1): int64 tensor of the first rows of the
     utterances 1 ... n-1.  The launch on the stacked image also multiplies across every border — g of an utterance's first row with x of
     the previous utterance's last row (taps ky = 0) and g of a last row with x of the next first row (ky = 2); exactly those products
-    are computed a second time from 2-row images {last row | first row} and subtracted.
+    are computed a second time from one 2-row image {last row | first row} per border and subtracted.
     x_packed (split8): x is a PACKED activation tensor and x_rec the record its producer filled — the kernel's producer waves
     then copy instead of converting (dasv_conv3x3_wgrad_x8p_nhwc); g_packed (with x_packed): g is packed too (the pool's backward
     wrote it that way), g_rec its record."""
@@ -331,14 +331,18 @@ def conv3x3_wgrad(x, g, mode="split", x_rec=None, g_rec=None, borders=None, x_pa
         tall = conv3x3_wgrad(x, g, mode, x_rec, g_rec, x_packed=x_packed, g_packed=g_packed)
         # (packed operands: whole pixel rows are gathered, so their slabs stay intact, and zero bits are a packed zero)
         x3, g3 = x.permute(0, 2, 3, 1)[0], g.permute(0, 2, 3, 1)[0]              # [rows, W, C] views of the channels_last memory
-        xl, xf, gl, gf = x3[borders - 1], x3[borders], g3[borders - 1], g3[borders]
-        zx, zg = torch.zeros_like(xl), torch.zeros_like(gl)
-        xb = torch.cat([torch.stack([xl, zx], dim=1), torch.stack([zx, xf], dim=1)]).permute(0, 3, 1, 2)     # [2 nb, C, 2, W] channels_last
-        gb = torch.cat([torch.stack([zg, gf], dim=1), torch.stack([gl, zg], dim=1)]).permute(0, 3, 1, 2)
+        # ONE 2-row image per border, {last row of utterance i | first row of utterance i + 1} for x and for g alike: its ky = 0 taps are
+        # exactly g_first x_last (row 1 looking up at row 0), its ky = 2 taps g_last x_first (row 0 looking down at row 1) — the two
+        # cross-border products of the stacked launch — and its ky = 1 taps (each row with itself: genuine products) are dropped
+        idx = torch.stack([borders - 1, borders], dim=1).reshape(-1)
+        xb = x3[idx].view(borders.numel(), 2, x3.shape[1], x3.shape[2]).permute(0, 3, 1, 2)                   # [nb, C, 2, W] channels_last
+        gb = g3[idx].view(borders.numel(), 2, g3.shape[1], g3.shape[2]).permute(0, 3, 1, 2)
         if mode == "split8":           # the same scales as the stacked launch (the records bound these rows too)
             x_rec = range_of(x) if x_rec is None else x_rec
             g_rec = range_of(g) if g_rec is None else g_rec
-        return tall - conv3x3_wgrad(xb, gb, mode, x_rec, g_rec, x_packed=x_packed, g_packed=g_packed)
+        cross = conv3x3_wgrad(xb, gb, mode, x_rec, g_rec, x_packed=x_packed, g_packed=g_packed)
+        cross[:, :, 1, :] = 0
+        return tall - cross
     lib = _lib.load()
     B, cin, H, W = x.shape
     cout = g.shape[1]
