@@ -294,13 +294,25 @@ class _VGG(nn.Module):
             _lib.check(_lib.load().dasv_range_absmax_f32(x.data_ptr(), x.numel(), rx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                        "dasv_range_absmax_f32")
         rh = next(r)
-        h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, span=spans[0], pack=True,
-                                                   x_rec=rx)
+        fused_first = self.fuse_first_backward and self.conv11.bias is not None
+        if not fused_first:
+            h = _hipconv.conv3x3_c1_bias_relu_autograd(x, self.conv11.weight, self.conv11.bias, rh, grad_premasked=True, span=spans[0], pack=True,
+                                                       x_rec=rx)
         for blk in range(1, self.n_blocks + 1):
             n1, n2 = "conv%d1" % blk, "conv%d2" % blk
             c1, c2 = getattr(self, n1), getattr(self, n2)
             sp, bd = spans[blk - 1], borders[blk - 1]
             l1, l2 = {}, {}
+            if blk == 1 and fused_first:
+                # conv11 + conv12 as one node: conv11's backward rides in conv12's data-gradient launch (conv.first_block_ragged_train)
+                ry = next(r)
+                h = _hipconv.first_block_ragged_train(x, self.conv11.weight, self.conv11.bias, c2.weight, c2.bias, self._pk(n2, dev),
+                                                      rx, rh, ry, sp, bd, l2)
+                rh, ry = ry, next(r)
+                h = _hipconv.maxpool2x2_ceil_autograd(h, relu_input=True, link_out=l2, x_rec=rh, y_rec=ry, pool_src=pools[0],
+                                                      pack_out=self.n_blocks > 1, pack_grad=True)
+                rh = ry
+                continue
             if blk > 1:
                 ry = next(r)
                 h = _hipconv.conv3x3_bias_relu(h, c1.weight, c1.bias, self._pk(n1, dev), "split8", grad_premasked=True, link_in=l1,

@@ -511,17 +511,21 @@ def _launch_pool_idx(x, hi, lo, bias, cout, x_rec, y_rec, x_packed, y_packed):
     return y, idx
 
 
-def _launch_dgrad_c1(g, hi, lo, cout, g_rec, mask, mel):
+def _launch_dgrad_c1(g, hi, lo, cout, g_rec, mask, mel, span=None):
     """conv12's data-gradient launch (g packed, mask = conv11's packed output) with conv11's backward in its write-out pass:
-    the per-tile partial rows [tiles][cout][10]."""
+    the per-tile partial rows [tiles][cout][10].  span: a ragged batch (one stacked image, border table)."""
     lib = _lib.load()
     B, cin, H, W = g.shape
-    rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0)
+    rows = lib.dasv_conv3x3_colsum_rows(3, B, H, W, 0 if span is None else 1)
     cpart = torch.empty((rows, cout, 10), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        rc = lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), 1,
-                                                 mel.data_ptr(), cpart.data_ptr(), B, H, W, cin, cout,
-                                                 torch.cuda.current_stream(g.device).cuda_stream)
+        st = torch.cuda.current_stream(g.device).cuda_stream
+        if span is not None:
+            rc = lib.dasv_conv3x3_masked_c1_ragged_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), 1,
+                                                            mel.data_ptr(), cpart.data_ptr(), span.data_ptr(), H, W, cin, cout, st)
+        else:
+            rc = lib.dasv_conv3x3_masked_c1_x8p_nhwc(g.data_ptr(), 1, g_rec.data_ptr(), hi.data_ptr(), lo.data_ptr(), mask.data_ptr(), 1,
+                                                 mel.data_ptr(), cpart.data_ptr(), B, H, W, cin, cout, st)
     _lib.check(rc, "dasv_conv3x3_masked_c1_x8p_nhwc")
     return cpart
 
@@ -626,6 +630,66 @@ class _FirstBlockFn(torch.autograd.Function):
                 _lib.check(lib.dasv_conv3x3_c1_bwd_reduce_parts(cpart.data_ptr(), prow, gw11.data_ptr(), None if gb11 is None else gb11.data_ptr(),
                                                                 C1, st), "dasv_conv3x3_c1_bwd_reduce_parts")
         return None, gw11, gb11, gw12, gb12, None, None, None, None, None, None
+
+
+class _FirstBlockRaggedFn(torch.autograd.Function):
+    """conv11 + conv12 of the packed training chain over a RAGGED batch (one stacked image, border tables) as one autograd node: forward =
+    the one-channel kernel (packed output) + conv12 (packed in, fp32 out: the pool that follows is its own launch under border tables);
+    backward = conv12's weight gradient (stacked image minus the cross-border products) and its data-gradient launch with conv11's whole
+    backward in the write-out pass (dasv_conv3x3_masked_c1_ragged_x8p_nhwc) — the gradient at conv11's output is never written.  The
+    incoming gradient is the packed, pre-masked tensor the pool's backward writes (maxpool2x2_ceil_autograd(..., pack_grad=True)), which
+    also leaves conv12's bias gradient in `link_in`."""
+
+    @staticmethod
+    def forward(ctx, mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, span, borders, link_in, fresh):
+        lib = _lib.load()
+        mel = mel.contiguous()
+        _, H, W = mel.shape
+        C1, C2 = w11.shape[0], w12.shape[0]
+        h = torch.empty((1, C1, H, W), dtype=torch.float32, device=mel.device, memory_format=torch.channels_last)
+        with torch.cuda.device(mel.device):
+            rc = lib.dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc(mel.data_ptr(), x_rec.data_ptr(), w11.detach().contiguous().data_ptr(),
+                                                              None if b11 is None else b11.detach().data_ptr(), h.data_ptr(), h_rec.data_ptr(),
+                                                              span.data_ptr(), H, W, C1, 1, torch.cuda.current_stream(mel.device).cuda_stream)
+        _lib.check(rc, "dasv_conv3x3_c1_bias_relu_ragged_x8_nhwc")
+        hi, lo = packed12.get(w12, "split8", b12, fresh=fresh)
+        y = _launch(h, hi, lo, b12, C2, "split8", x_rec=h_rec, y_rec=y_rec, span=span, x_packed=True)
+        ctx.save_for_backward(mel, h, w12)
+        ctx.h_rec, ctx.span, ctx.borders, ctx.link_in = h_rec, span, borders, link_in
+        ctx.bias = (b11 is not None, b12 is not None)
+        ctx.w11_shape = w11.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mel, h, w12 = ctx.saved_tensors
+        lib = _lib.load()
+        C1, dev = h.shape[1], gy.device
+        g_rec = _rec_of(gy)
+        if g_rec is None or not gy.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("the ragged first block expects the packed gradient of maxpool2x2_ceil_autograd(..., pack_grad=True)")
+        gw12 = conv3x3_wgrad(h, gy, "split8", x_rec=ctx.h_rec, g_rec=g_rec, borders=ctx.borders, x_packed=True, g_packed=True) \
+            if ctx.needs_input_grad[3] else None
+        gb12 = ctx.link_in.pop("gb", None) if (ctx.bias[1] and ctx.needs_input_grad[4]) else None
+        gw11 = gb11 = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            hi, lo = _pack_dgrad_x8(w12.detach())
+            cpart = _launch_dgrad_c1(gy, hi, lo, C1, g_rec, h, mel, span=ctx.span)
+            gw11 = torch.empty(ctx.w11_shape, dtype=torch.float32, device=dev)
+            gb11 = torch.empty(C1, dtype=torch.float32, device=dev) if ctx.bias[0] else None
+            with torch.cuda.device(dev):
+                _lib.check(lib.dasv_conv3x3_c1_bwd_reduce_parts(cpart.data_ptr(), cpart.shape[0], gw11.data_ptr(),
+                                                                None if gb11 is None else gb11.data_ptr(), C1,
+                                                                torch.cuda.current_stream(dev).cuda_stream), "dasv_conv3x3_c1_bwd_reduce_parts")
+        return (None, gw11, gb11, gw12, gb12) + (None,) * 8
+
+
+def first_block_ragged_train(mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, span, borders, link_in):
+    """Differentiable (w.r.t. the four parameters) conv11 + conv12 on packed activations over a ragged batch: mel [1, rows, W] (utterances
+    stacked along the rows) -> conv12's fp32 map [1, C, rows, W]; its one consumer is maxpool2x2_ceil_autograd(..., relu_input=True,
+    link_out=link_in, pack_grad=True)."""
+    fresh = torch.is_grad_enabled() and w12.requires_grad
+    return _FirstBlockRaggedFn.apply(mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, span, borders, link_in, fresh)
 
 
 def first_block_train(mel, w11, b11, w12, b12, packed12, x_rec, h_rec, y_rec, y_packed=True):

@@ -1398,6 +1398,12 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     melw[tid] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? p.c1_mel[((size_t)gb * H + hh) * W + ww] : 0.f;
                 }
             }
+            if constexpr (X8 && GEOM == 0) {      // raster tiles: the tile's pixels plus a row and a pixel on either side, contiguous
+                if (p.c1_part != nullptr && tid < TBM + 2 * W + 2) {
+                    const long long gi = (long long)m0 - W - 1 + tid;
+                    melw[tid] = (gi >= 0 && gi < (long long)p.M) ? p.c1_mel[gi] : 0.f;
+                }
+            }
             __syncthreads();
             DASV_STAMP(62);
             if (p.y_rec != nullptr && tid == 0 && s_amax > rec_seen) atomicMax(p.y_rec, s_amax);
@@ -1553,12 +1559,14 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
 #pragma unroll
                                     for (int t = 0; t < 9; ++t) wacc[t] += v * mw[(t / 3) * PW + t % 3];
                                 } else {
-                                    const int w_ = mm[k] % W, h_ = (mm[k] / W) % H;
-                                    const float* mp = p.c1_mel + mm[k];
+                                    const int w_ = mm[k] % W, rr = mm[k] / W;
+                                    int h_ = rr % H, hlo = 0, hhi = H;
+                                    if (p.row_span != nullptr) { h_ = rr; hlo = p.row_span[2 * rr]; hhi = p.row_span[2 * rr + 1]; }   // ragged: the utterance's rows
+                                    const float* mp = melw + pix + W + 1;              // the pixel's place in the staged window
 #pragma unroll
                                     for (int t = 0; t < 9; ++t) {
                                         const int hh = h_ + t / 3 - 1, ww = w_ + t % 3 - 1;
-                                        const float in = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? mp[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
+                                        const float in = (hh >= hlo && hh < hhi && (unsigned)ww < (unsigned)W) ? mp[(t / 3 - 1) * W + (t % 3 - 1)] : 0.f;
                                         wacc[t] += v * in;
                                     }
                                 }
@@ -1789,8 +1797,8 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
                           uint32_t* y_rec = nullptr, int pool = 0, int pool_tile = 0, uint8_t* pool_idx = nullptr, int mask_packed = 0,
                           const float* c1_mel = nullptr, float* c1_part = nullptr) {
     if ((x == nullptr && mel == nullptr) || w_hi == nullptr || (y == nullptr && c1_part == nullptr) || ((mode == 0 || mode == 3) && w_lo == nullptr)) return DASV_E_NULL;
-    if (c1_part != nullptr && (c1_mel == nullptr || mode != 3 || mask == nullptr || colsum != nullptr || workspace != nullptr || row_span != nullptr ||
-                               W > 80 || pool)) return DASV_E_SHAPE;
+    if (c1_part != nullptr && (c1_mel == nullptr || mode != 3 || mask == nullptr || colsum != nullptr || workspace != nullptr || W > 80 || pool))
+        return DASV_E_SHAPE;
     if (mel != nullptr && (w1 == nullptr || W > 80)) return mel != nullptr && w1 == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cin % dasv::CBK != 0 || Cout % dasv::CBN != 0) return DASV_E_SHAPE;
@@ -1890,6 +1898,7 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
         p.tiles_per_xcd = (p.mtiles * p.ntiles + 7) / 8;
         size_t lds = lds1 + (dbuf ? 32768 + 128 : 0);   // + the zero row of the pipelined loops
         if (dbuf && lds < (size_t)tbm * 528) lds = (size_t)tbm * 528;   // the coalescing epilogue's [pixel][528 B] image (narrow maps)
+        if (c1_part != nullptr && lds < (size_t)tbm * 528 + (size_t)(tbm + 2 * W + 2) * 4) lds = (size_t)tbm * 528 + (size_t)(tbm + 2 * W + 2) * 4;
         if (t160) {
             lds = (size_t)(160 + 2 * W + 2) * 128 * (two ? 2 : 1) + 65536 + 128;
             if (lds < (size_t)160 * 528) lds = (size_t)160 * 528;
@@ -2108,6 +2117,16 @@ int dasv_conv3x3_masked_c1_x8p_nhwc(const void* x, int x_packed, const uint32_t*
     if (W > 80) return DASV_E_SHAPE;
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, static_cast<const float*>(mask),
                           nullptr, nullptr, nullptr, 0, B, H, W, Cin, Cout, 0, stream, nullptr, x_packed ? 1 : 0, 0, x_range, nullptr, 0, 0,
+                          nullptr, mask_packed ? 1 : 0, mel, c1_partial);
+}
+
+int dasv_conv3x3_masked_c1_ragged_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                           const void* mask, int mask_packed, const float* mel, float* c1_partial, const int* row_span, int rows,
+                                           int W, int Cin, int Cout, dasv_stream_t stream) {
+    if (mask == nullptr || mel == nullptr || c1_partial == nullptr || row_span == nullptr) return DASV_E_NULL;
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, nullptr, static_cast<const float*>(mask),
+                          nullptr, nullptr, nullptr, 0, 1, rows, W, Cin, Cout, 0, stream, row_span, x_packed ? 1 : 0, 0, x_range, nullptr, 0, 0,
                           nullptr, mask_packed ? 1 : 0, mel, c1_partial);
 }
 

@@ -398,6 +398,10 @@ int dasv_conv3x3_masked_c1_x8p_nhwc(const void* x, int x_packed, const uint32_t*
                                     dasv_stream_t stream);
 /* out[c] = sum over the rows of a [rows][C] partial-sum buffer (colsum_partial of the entry points above), in a fixed order. */
 int dasv_colsum_reduce(const float* partial, int rows, int C, float* out, dasv_stream_t stream);
+/* ... over a ragged batch (B = 1, H = the stacked rows, borders from row_span; partial rows: dasv_conv3x3_colsum_rows(3, 1, rows, W, 1)) */
+int dasv_conv3x3_masked_c1_ragged_x8p_nhwc(const void* x, int x_packed, const uint32_t* x_range, const void* w_f16, const void* w_e4m3,
+                                           const void* mask, int mask_packed, const float* mel, float* c1_partial, const int* row_span, int rows,
+                                           int W, int Cin, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, float* gb, int Cout, dasv_stream_t stream);
 int dasv_conv3x3_wgrad_x8p_nhwc(const void* x_packed, const uint32_t* x_range, const void* g, int g_packed, const uint32_t* g_range, float* gw,
                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, dasv_stream_t stream);

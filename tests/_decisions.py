@@ -67,6 +67,16 @@ class DecisionCapture:
             return y
 
         self.mp.setattr(C, "first_block_train", first_block)
+        ofr = C.first_block_ragged_train
+
+        def first_block_ragged(*a, **k):
+            # conv11 + conv12 over a ragged batch as one node: conv11's packed output is saved on it, conv12's fp32 map is the result
+            y = ofr(*a, **k)
+            self.events.append(("conv", packed_sign(y.grad_fn.saved_tensors[1])))
+            self.events.append(("conv", y.detach()))
+            return y
+
+        self.mp.setattr(C, "first_block_ragged_train", first_block_ragged)
         return self
 
     def __exit__(self, *exc):

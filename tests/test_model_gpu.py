@@ -204,8 +204,8 @@ def test_variable_length_minibatch_train_step_vs_float64(monkeypatch):
     assert abs(float(loss2) - float(loss)) < 1e-5 * abs(float(loss)) and float((net.fc1.weight - before).abs().max()) > 0
 
 
-@pytest.mark.parametrize("packed", [True, False])
-def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buckets(packed, monkeypatch):
+@pytest.mark.parametrize("wiring", ["packed, first block as one node", "packed", "fp32"])
+def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buckets(wiring, monkeypatch):
     """The same semantics as the test above — every utterance of a training minibatch at its own length, one dense tail — but as
     ONE set of launches: the utterances stacked along time, the front-end's forward, data-gradient, weight-gradient, pool and conv11
     kernels taking the utterance borders from tables (ragged.utterance_vectors_ragged_train; the weight gradient subtracts the
@@ -214,8 +214,10 @@ def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buck
     took, flips counted; (2) against the one-dense-pass-per-length path of the same model: same loss, gradients to 4e-5.
     packed: the stacked batch on PACKED activations (CNNs._forward_map_packed_ragged_train: packed tensors between the layers, the pool's
     backward writing a packed gradient, packed operands in the weight gradients and the packed mask in the data gradients — the shipped
-    wiring) or on fp32 activations; (2) holds element by element only between forwards of the same arithmetic (the fp32 wiring and the
-    per-length passes), with the packed chain the loss."""
+    wiring — with conv11 + conv12 as one autograd node whose backward forms conv11's gradients inside conv12's data-gradient launch,
+    conv.first_block_ragged_train, or with conv11 as its own node) or on fp32 activations; (2) holds element by element only between
+    forwards of the same arithmetic (the fp32 wiring and the per-length passes), with the packed chain the loss."""
+    packed = wiring != "fp32"
     from doubleattentionspeakerverification_amd.model import SpeakerClassifier
     from _decisions import DecisionCapture
     p = argparse.Namespace(front_end="VGG4L", kernel_size=1024, pooling_method="DoubleMHA", heads_number=32, mask_prob=0.3,
@@ -229,6 +231,7 @@ def test_variable_length_minibatch_in_one_set_of_launches_vs_float64_and_vs_buck
     keep[:, 1] = True
     assert net.ragged_training == "stacked" and net.front_end.ragged_training_ok()
     net.front_end.packed_training = packed
+    net.front_end.fuse_first_backward = wiring.endswith("one node")
     took = []
     inner = net.front_end._forward_map_packed_ragged_train
     monkeypatch.setattr(net.front_end, "_forward_map_packed_ragged_train", lambda *a: (took.append(1), inner(*a))[1])
