@@ -24,37 +24,43 @@ namespace dasv {
 typedef float af4 __attribute__((ext_vector_type(4)));
 
 constexpr int AT = 64;    // tile edge (rows and columns per workgroup)
-constexpr int AK = 16;    // reduction chunk staged in LDS
+constexpr int AK = 64;    // reduction chunk of the two backward products (16 in round 3: four times the exposed round trips)
 constexpr float kAmEps = 1e-12f;   // loss.py:40,42: norms clamped at 1e-12
 
 // One 64 x 64 tile of C = A (64 x K, row r at a + r * lda, k contiguous) * B (K x 64, row k at b + k * ldb, columns contiguous),
 // rows < ra and columns < cb valid, K any.  256 threads as 16 x 16, thread (ty, tx) owns rows ty*4.. and columns tx*4...
 // asq / bsq (optional): sums of squares of A's rows / B's columns, accumulated from the staged tiles (every thread gets the sums
 // of ITS four rows / columns).
+// Chunks of FK = 16 with the loads TWO chunks ahead in registers: written as load - barrier - FMAs - barrier the 25 chunks of E = 400
+// were 25 exposed memory round trips (82 us for a 0.3 GFLOP product on 94 workgroups); one chunk ahead 44 us; 64-wide chunks 65 us.
+constexpr int FK = 16;
 __device__ __forceinline__ void tile_product(const float* __restrict__ a, long long lda, int ra, const float* __restrict__ b,
                                              long long ldb, int cb, int K, float (&acc)[4][4], float* asq, float* bsq,
-                                             float (*As)[AK + 1], float (*Bs)[AT + 4]) {
+                                             float (*As)[FK + 1], float (*Bs)[AT + 4]) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += AK) {
-        // A chunk: 64 rows x 16 k, element (r, kk) by thread r * 4 + kk / 4 ... as 4 consecutive k per thread
-        {
-            const int r = tid >> 2, kk = (tid & 3) * 4;
+    const int ar = tid >> 2, akk = (tid & 3) * 4;          // A chunk: 64 rows x 16 k, four consecutive k of row ar per thread
+    const int bc = tid & 63, bk0 = tid >> 6;               // B chunk: 16 k x 64 columns, column bc of rows bk0, bk0 + 4, ...
+    float pa0[4], pb0[4], pa1[4], pb1[4];
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};     // sums of squares, in registers (copied out below)
+    auto fetch = [&](float (&qa)[4], float (&qb)[4], int k0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) As[r][kk + q] = (r < ra && k0 + kk + q < K) ? a[(long long)r * lda + k0 + kk + q] : 0.f;
-        }
-        // B chunk: 16 k x 64 columns, a wave reads 64 consecutive columns of one k
+        for (int q = 0; q < 4; ++q) qa[q] = (ar < ra && k0 + akk + q < K) ? a[(long long)ar * lda + k0 + akk + q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kk = q * 4 + (tid >> 6), c = tid & 63;
-            Bs[kk][c] = (k0 + kk < K && c < cb) ? b[(long long)(k0 + kk) * ldb + c] : 0.f;
-        }
+        for (int q = 0; q < 4; ++q) qb[q] = (k0 + q * 4 + bk0 < K && bc < cb) ? b[(long long)(k0 + q * 4 + bk0) * ldb + bc] : 0.f;
+    };
+    auto chunk = [&](float (&qa)[4], float (&qb)[4], int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) As[ar][akk + q] = qa[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[q * 4 + bk0][bc] = qb[q];
         __syncthreads();
+        if (k0 + 2 * FK < K) fetch(qa, qb, k0 + 2 * FK);     // this register set is free again: two chunks ahead
 #pragma unroll
-        for (int kk = 0; kk < AK; ++kk) {
+        for (int kk = 0; kk < FK; ++kk) {
             float av[4], bv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) av[i] = As[ty * 4 + i][kk];
@@ -64,17 +70,21 @@ __device__ __forceinline__ void tile_product(const float* __restrict__ a, long l
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-            if (asq != nullptr) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) asq[i] = fmaf(av[i], av[i], asq[i]);
-            }
-            if (bsq != nullptr) {
+            for (int i = 0; i < 4; ++i) sa[i] = fmaf(av[i], av[i], sa[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bsq[j] = fmaf(bv[j], bv[j], bsq[j]);
-            }
+            for (int j = 0; j < 4; ++j) sb[j] = fmaf(bv[j], bv[j], sb[j]);
         }
         __syncthreads();
+    };
+    fetch(pa0, pb0, 0);
+    if (FK < K) fetch(pa1, pb1, FK);
+    for (int k0 = 0; k0 < K; k0 += 2 * FK) {
+        chunk(pa0, pb0, k0);
+        if (k0 + FK < K) chunk(pa1, pb1, k0 + FK);
     }
+    if (asq != nullptr) { asq[0] += sa[0]; asq[1] += sa[1]; asq[2] += sa[2]; asq[3] += sa[3]; }
+    if (bsq != nullptr) { bsq[0] += sb[0]; bsq[1] += sb[1]; bsq[2] += sb[2]; bsq[3] += sb[3]; }
 }
 
 struct AmParams {
@@ -92,8 +102,8 @@ struct AmParams {
 };
 
 __global__ void __launch_bounds__(256) amsoftmax_fwd_kernel(const AmParams p) {
-    __shared__ float As[AT][AK + 1];
-    __shared__ __attribute__((aligned(16))) float Bs[AK][AT + 4];
+    __shared__ float As[AT][FK + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[FK][AT + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int n0 = blockIdx.x * AT, b0 = blockIdx.y * AT;
     float acc[4][4], asq[4] = {0.f, 0.f, 0.f, 0.f}, bsq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -152,15 +162,25 @@ __global__ void __launch_bounds__(256) amsoftmax_ce_finish_kernel(const float* _
                                                                   float* __restrict__ lse, float* __restrict__ loss, int B, int ntile) {
     __shared__ float red[256];
     float local = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    // four lanes per row share its column tiles (one thread per row walked the ~94 tiles twice, load after load: 28 us of a step)
+    const int sub = threadIdx.x & 3;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + (threadIdx.x >> 2);
+        const bool live = b < B;
         float mx = -INFINITY;
-        for (int t = 0; t < ntile; ++t) mx = fmaxf(mx, part[((long long)b * ntile + t) * 2]);
+        if (live)
+            for (int t = sub; t < ntile; t += 4) mx = fmaxf(mx, part[((long long)b * ntile + t) * 2]);
+        mx = group_max<4>(mx);
         float se = 0.f;
-        for (int t = 0; t < ntile; ++t) se += part[((long long)b * ntile + t) * 2 + 1] * __expf(part[((long long)b * ntile + t) * 2] - mx);
-        const float l = mx + __logf(se);
-        lse[b] = l;
-        const long long lab = label[b];
-        local += l - ((lab >= 0 && lab < (long long)N) ? lab_logit[b] : __builtin_nanf(""));
+        if (live)
+            for (int t = sub; t < ntile; t += 4) se += part[((long long)b * ntile + t) * 2 + 1] * __expf(part[((long long)b * ntile + t) * 2] - mx);
+        se = group_sum<4>(se);
+        if (live && sub == 0) {
+            const float l = mx + __logf(se);
+            lse[b] = l;
+            const long long lab = label[b];
+            local += l - ((lab >= 0 && lab < (long long)N) ? lab_logit[b] : __builtin_nanf(""));
+        }
     }
     red[threadIdx.x] = local;
     __syncthreads();
@@ -214,6 +234,7 @@ __global__ void __launch_bounds__(256) amsoftmax_bwd_w_kernel(const float* __res
                                                               float* __restrict__ gW, int B, int E, int N) {
     __shared__ float As[AT][AK + 1];
     __shared__ __attribute__((aligned(16))) float Bs[AK][AT + 4];
+    __shared__ __attribute__((aligned(16))) float Cs[AK][AT + 4];      // the cos chunk beside the dcos chunk (t[n] = sum_b dcos cos)
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int n0 = blockIdx.x * AT, e0 = blockIdx.y * AT;
     float acc[4][4], t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -224,32 +245,33 @@ __global__ void __launch_bounds__(256) amsoftmax_bwd_w_kernel(const float* __res
     for (int k0 = 0; k0 < B; k0 += AK) {
         {   // A chunk (64 e x 16 b) = x[b][e] * xinv[b]: a wave reads 64 consecutive e of one b
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < AK / 4; ++q) {
                 const int kk = q * 4 + (tid >> 6), e = tid & 63;
                 As[e][kk] = (k0 + kk < B && e0 + e < E) ? x[(long long)(k0 + kk) * E + e0 + e] * xinv[k0 + kk] : 0.f;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AK / 4; ++q) {
             const int kk = q * 4 + (tid >> 6), c = tid & 63;
-            Bs[kk][c] = (k0 + kk < B && n0 + c < N) ? dcos[(long long)(k0 + kk) * N + n0 + c] : 0.f;
+            const bool ok = k0 + kk < B && n0 + c < N;
+            Bs[kk][c] = ok ? dcos[(long long)(k0 + kk) * N + n0 + c] : 0.f;
+            // (round 3 read cos straight from memory inside the FMA loop: 64 dependent scalar loads per chunk and thread — 114 us)
+            Cs[kk][c] = ok ? costh[(long long)(k0 + kk) * N + n0 + c] : 0.f;
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 8
         for (int kk = 0; kk < AK; ++kk) {
             float av[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) av[i] = As[ty * 4 + i][kk];
             const af4 b4 = *reinterpret_cast<const af4*>(&Bs[kk][tx * 4]);
+            const af4 c4 = *reinterpret_cast<const af4*>(&Cs[kk][tx * 4]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], b4[j], acc[i][j]);
-            if (k0 + kk < B) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n0 + tx * 4 + j < N) t[j] = fmaf(b4[j], costh[(long long)(k0 + kk) * N + n0 + tx * 4 + j], t[j]);
-            }
+            for (int j = 0; j < 4; ++j) t[j] = fmaf(b4[j], c4[j], t[j]);
         }
         __syncthreads();
     }
@@ -283,22 +305,21 @@ __global__ void __launch_bounds__(256) amsoftmax_bwd_x_kernel(const float* __res
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     for (int k0 = nlo; k0 < nhi; k0 += AK) {
         {   // A chunk (64 b x 16 n) = dcos[b][n] * winv[n]
-            const int r = tid >> 2, kk = (tid & 3) * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = k0 + kk + q;
-                As[r][kk + q] = (b0 + r < B && n < nhi) ? dcos[(long long)(b0 + r) * N + n] * winv[n] : 0.f;
+            for (int q = 0; q < AK / 4; ++q) {
+                const int idx = q * 256 + tid, r = idx / AK, n = k0 + idx % AK;
+                As[r][idx % AK] = (b0 + r < B && n < nhi) ? dcos[(long long)(b0 + r) * N + n] * winv[n] : 0.f;
             }
         }
         {   // B chunk (16 n x 64 e) = W[e][n]: element (kk, e); consecutive lanes take consecutive n of one e (n is contiguous in W)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = q * 256 + tid, e = idx >> 4, kk = idx & 15;
+            for (int q = 0; q < AK / 4; ++q) {
+                const int idx = q * 256 + tid, e = idx / AK, kk = idx % AK;
                 Bs[kk][e] = (e0 + e < E && k0 + kk < nhi) ? W[(long long)(e0 + e) * N + k0 + kk] : 0.f;
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 8
         for (int kk = 0; kk < AK; ++kk) {
             float av[4];
 #pragma unroll
@@ -337,7 +358,10 @@ __global__ void __launch_bounds__(256) amsoftmax_bwd_x_reduce(const float* __res
     }
 }
 
-static int am_chunks(int N) { return (N + 511) / 512; }
+// columns per workgroup of the dx product: 128 (47 chunks x 7 tiles = 329 workgroups for N = 5994; with 512 the launch was 84 workgroups
+// of 32 sequential LDS chunks each: 92 us)
+constexpr int kAmChunkCols = 128;
+static int am_chunks(int N) { return (N + kAmChunkCols - 1) / kAmChunkCols; }
 
 }  // namespace dasv
 
@@ -404,7 +428,7 @@ int dasv_amsoftmax_bwd(const float* x, const float* W, const int64_t* label, con
                        dim3(256), 0, s, x, W, dcos, costh, xinv, winv, gW, B, E, N);
     hipLaunchKernelGGL(dasv::amsoftmax_bwd_x_kernel,
                        dim3((unsigned)((E + dasv::AT - 1) / dasv::AT), (unsigned)((B + dasv::AT - 1) / dasv::AT), (unsigned)nch), dim3(256), 0, s,
-                       W, dcos, winv, part, B, E, N, 512);
+                       W, dcos, winv, part, B, E, N, dasv::kAmChunkCols);
     const long long nx = (long long)B * E;
     const int bx = (int)((nx + 255) / 256 < 1024 ? (nx + 255) / 256 : 1024);
     hipLaunchKernelGGL(dasv::amsoftmax_bwd_x_reduce, dim3(bx), dim3(256), 0, s, part, x, xinv, u, gx, B, E, nch);
