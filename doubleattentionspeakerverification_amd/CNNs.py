@@ -74,7 +74,8 @@ class _VGG(nn.Module):
         self.fuse_first_block = False
         # inference: activations between the split8 layers in the consumer's operand form (conv.conv3x3_x8); same results
         self.packed_activations = True
-        # inference in the fp16-operand mode: activations between the layers as fp16 tensors (conv.conv3x3_f16)
+        # inference in the fp16- / bf16-operand modes: activations between the layers as fp16 (scaled by range records, conv.conv3x3_f16)
+        # or bf16 (plain values, conv.conv3x3_bf16) tensors
         self.half_activations = True
         # inference chains: convX2 + ReLU + the block's 2x2 ceil max-pool as ONE launch (conv.conv3x3_x8 / conv3x3_f16, pool=True).
         # `fuse_pool_layers`: the (block, mode) pairs it is switched on for — where the same-process A/B on [64,300,80] says it pays
@@ -146,7 +147,7 @@ class _VGG(nn.Module):
         batches: a packed output is written by the convolution's own epilogue, so those launches could not divide their channel
         slabs over workgroups (split-K) — the fp32 chain is faster there (single utterances: train.py:117-133)."""
         mode = self._mode()
-        if (mode != "split8" and not (mode == "fp16" and self.half_activations)) or self.fuse_first_block or fdim > 80 \
+        if (mode != "split8" and not (mode in ("fp16", "bf16") and self.half_activations)) or self.fuse_first_block or fdim > 80 \
                 or self.conv11.out_channels % 64 != 0:
             return False
         if batch is not None:
@@ -363,6 +364,21 @@ class _VGG(nn.Module):
             rh = ry
         return h
 
+    def _forward_map_bf16(self, x):
+        """The bf16 STORAGE chain of the bf16-operand mode (inference; BASELINE config 3 names bf16): conv11 -> bf16 -> conv12 -> bf16 ->
+        pool -> bf16 -> ... -> convN2 -> bf16 -> last pool -> fp32 map.  Plain bf16 values between the layers (no scale, no records): each
+        layer's output is rounded ONCE, to the 8 bits its consumer's operands would keep anyway — the values the fp32-activation bf16
+        mode multiplies, at half the activation traffic."""
+        dev = x.device
+        h = _hipconv.conv3x3_c1_bias_relu_bf16(x.contiguous(), self.conv11.weight, self.conv11.bias)
+        for blk in range(1, self.n_blocks + 1):
+            c1, c2 = getattr(self, "conv%d1" % blk), getattr(self, "conv%d2" % blk)
+            if blk > 1:
+                h = _hipconv.conv3x3_bf16(h, c1.weight, c1.bias, self._pk("conv%d1" % blk, dev), x_bf16=True, y_bf16=True)
+            h = _hipconv.conv3x3_bf16(h, c2.weight, c2.bias, self._pk("conv%d2" % blk, dev), x_bf16=True, y_bf16=True)
+            h = _hipconv.maxpool2x2_ceil_bf16(h, y_bf16=blk < self.n_blocks)
+        return h
+
     def _hip_front(self, x):
         """conv11 and the max-pools on the HIP kernels: fp32 activations on the GPU, not under autocast, and the input
         features themselves do not need a gradient."""
@@ -416,6 +432,9 @@ class _VGG(nn.Module):
         if hip and not grad and self.half_activations and self._mode() == "fp16" and not torch.is_autocast_enabled() \
                 and self._packed_chain_ok(Fdim, B, T):
             return self._forward_map_f16(paddedInputTensor)
+        if hip and not grad and self.half_activations and self._mode() == "bf16" and not torch.is_autocast_enabled() \
+                and self._packed_chain_ok(Fdim, B, T):
+            return self._forward_map_bf16(paddedInputTensor)
         fused_first = False
         # split8: one range record per tensor (see _forward_map_packed); rh = the record of h, None where h has none
         x8 = hip and self._mode() == "split8"

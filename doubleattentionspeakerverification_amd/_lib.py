@@ -94,6 +94,10 @@ SIGNATURES = {
     "dasv_maxpool2x2_ceil_idx_ragged_x8_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_maxpool2x2_ceil_bwd_idx_ragged_x8_nhwc": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_masked_ragged_x8p_nhwc": (c_int, [c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_bias_relu_bf16_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                                 c_int, c_int, c_void_p]),
+    "dasv_conv3x3_c1_bias_relu_bf16_nhwc": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dasv_maxpool2x2_ceil_bf16_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_colsum_reduce": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dasv_conv3x3_masked_c1_ragged_x8p_nhwc": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dasv_conv3x3_c1_bwd_reduce_parts": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -901,6 +901,58 @@ def conv3x3_f16(x, weight, bias, packed=None, x_f16=False, y_f16=False, x_rec=No
     return y
 
 
+def conv3x3_bf16(x, weight, bias, packed=None, x_bf16=False, y_bf16=False):
+    """Inference-only relu(conv2d(x, weight, bias, padding 1)) with bf16 operands on bf16 activation tensors (the bf16 STORAGE chain:
+    torch.bfloat16 tensors of logical shape [B,C,H,W], channels_last — plain round-to-nearest-even values, no scale, no record).
+    Producers: this function (y_bf16), conv3x3_c1_bias_relu_bf16, maxpool2x2_ceil_bf16."""
+    lib = _lib.load()
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    want = torch.bfloat16 if x_bf16 else torch.float32
+    if not x.is_cuda or x.dtype != want or not exact(cin, cout) or W > 80 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("conv3x3_bf16: unsupported shape/dtype/layout %s %s" % (tuple(x.shape), x.dtype))
+    packed = packed or PackedConvWeights()
+    hi, _ = packed.get(weight, "bf16")
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16 if y_bf16 else torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        nws = 0 if y_bf16 else lib.dasv_conv3x3_workspace_bytes(B, H, W, cin, cout)
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        rc = lib.dasv_conv3x3_bias_relu_bf16_nhwc(x.data_ptr(), int(x_bf16), hi.data_ptr(), None if bias is None else bias.detach().data_ptr(),
+                                                  y.data_ptr(), int(y_bf16), None if ws is None else ws.data_ptr(), nws, B, H, W, cin, cout, 1,
+                                                  torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_bias_relu_bf16_nhwc")
+    return y
+
+
+def conv3x3_c1_bias_relu_bf16(x, weight, bias):
+    """relu(conv2d(x[:,None], weight, bias, padding 1)) for x [B,H,W] fp32 -> a bf16 tensor [B,Cout,H,W] channels_last."""
+    lib = _lib.load()
+    B, H, W = x.shape
+    cout = weight.shape[0]
+    x = x.contiguous()
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_conv3x3_c1_bias_relu_bf16_nhwc(x.data_ptr(), weight.detach().contiguous().data_ptr(),
+                                                     None if bias is None else bias.detach().data_ptr(), y.data_ptr(), B, H, W, cout, 1,
+                                                     torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_conv3x3_c1_bias_relu_bf16_nhwc")
+    return y
+
+
+def maxpool2x2_ceil_bf16(x, y_bf16=True):
+    """F.max_pool2d(x, 2, stride=2, ceil_mode=True) of a bf16 channels_last tensor; y bf16 (exact: a maximum of bf16 values) or fp32."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("maxpool2x2_ceil_bf16: a bf16 channels_last tensor")
+    y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.bfloat16 if y_bf16 else torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.dasv_maxpool2x2_ceil_bf16_nhwc(x.data_ptr(), y.data_ptr(), int(y_bf16), B, H, W, C, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "dasv_maxpool2x2_ceil_bf16_nhwc")
+    return y
+
+
 def maxpool2x2_ceil(x, pack=False, x_rec=None, y_rec=None):
     """Inference-only F.max_pool2d(x, 2, stride=2, ceil_mode=True) for a channels_last fp32 tensor [B,C,H,W].
     x_rec / y_rec (together): the pooled map's range record is its input's.

@@ -100,6 +100,18 @@ __device__ __forceinline__ void cvt2(float a, float b, uint32_t& hi, uint32_t& l
         split2(a, b, hi, lo);
     }
 }
+// four fp32 values -> the 16-bit STORAGE form of a half-precision activation chain: fp16 of v * s (PREC_F16: s = 2^Ey from the range
+// record) or bf16 of v (PREC_BF16: round to nearest even, no scale — bf16 has fp32's exponent range; a NaN stays a NaN)
+template <int PREC>
+__device__ __forceinline__ uint2 pack16x4(f32x4 v, float s) {
+    if (PREC == PREC_F16) {
+        const f32x4 q = v * s;
+        const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
+        return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+    }
+    const bf16x2_t a = __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t), b2 = __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t);
+    return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+}
 template <int PREC>
 __device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) {
     if (PREC == PREC_F16)
@@ -490,6 +502,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
     constexpr bool W8 = WM * NWN == 8;      // eight waves: the pipelined loops (the tile's DMA is divided over eight waves)
     constexpr bool X8 = PREC == PREC_X8;
     constexpr bool SPLIT = PREC == PREC_SPLIT;
+    constexpr bool H16 = PREC == PREC_F16 || PREC == PREC_BF16;      // modes with a half-precision STORAGE chain (x_packed / y_packed == 2)
     constexpr bool TWO = SPLIT || X8;      // two LDS planes per operand: bf16 hi | lo, or fp16 hi | the two e4m3 planes
     static_assert(!X8 || (W8 && !C1), "the fp16 + e4m3 mode exists for the 8-wave layouts, activations from memory");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -671,7 +684,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
         if constexpr (GEOM == 1) {
             int w0r = wr0;
             asm volatile("" : "+v"(w0r));           // (per slab, not hoisted: see below)
-            const bool half = PREC == PREC_F16 && p.x_packed == 2;      // fp16 tensor: a pixel's slab is 128 bytes = chunks 0-7
+            const bool half = H16 && p.x_packed == 2;      // 16-bit tensor: a pixel's slab is 128 bytes = chunks 0-7
             const char* xb = reinterpret_cast<const char*>(p.x) + (half ? ((size_t)((int)(xc - p.x) - wach * 4) * 2 + (size_t)(wach & 7) * 16) : 0);
 #pragma unroll
             for (int k = 0; k < WACHN; ++k) {
@@ -686,7 +699,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
             }
             return;
         }
-        if constexpr (PREC == PREC_F16) {
+        if constexpr (H16) {
             if (p.x_packed == 2) {
                 // half-precision x: a pixel's 64-channel slab is 128 bytes = chunks 0-7; the staging is a copy (threads with
                 // wach >= 8 have nothing to fetch)
@@ -728,7 +741,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     char* rowl = Alo + wr * 128;
                     if (X8 && p.x_packed) {
                         *reinterpret_cast<f32x4*>((wach < 8 ? rowh : rowl) + (((wach & 7) ^ key) << 4)) = ra[k];
-                    } else if (PREC == PREC_F16 && p.x_packed == 2) {
+                    } else if (H16 && p.x_packed == 2) {
                         if (wach < 8) *reinterpret_cast<f32x4*>(rowh + ((wach ^ key) << 4)) = ra[k];
                     } else {
                         uint32_t h0, l0, h1, l1;
@@ -759,7 +772,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 if (k < nfull || (k == nfull && wtail)) *reinterpret_cast<f32x4*>(dst + k * (RSTEP * 128)) = ra[k];
             return;
         }
-        if constexpr (PREC == PREC_F16) {
+        if constexpr (H16) {
             if (p.x_packed == 2) {
                 if (wach < 8) {
                     char* dst = Ahi + lds_off(wr0, wach);
@@ -1366,10 +1379,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     if (p.pool) {
                         // fused max-pool: the image holds the fp32 values; the output form is applied to the pooled values below
                         *reinterpret_cast<f32x4*>(row + nl * 4) = v;
-                    } else if (PREC == PREC_F16 && p.y_packed == 2) {
-                        const f32x4 q = v * sy;
-                        const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
-                        *reinterpret_cast<uint2*>(row + nl * 2) = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                    } else if (H16 && p.y_packed == 2) {
+                        *reinterpret_cast<uint2*>(row + nl * 2) = pack16x4<PREC>(v, sy);
                     } else if (p.y_packed) {
                         // PACKED output (dasv_common.hpp): the row image is the pixel's two 256-byte slabs; the small stores that
                         // made a packed epilogue cost the layer 18 % when they went to memory are LDS stores here
@@ -1465,11 +1476,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                         if (r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + rowp * OP));
                         if (c1 && r1) v = mx4(v, *reinterpret_cast<const f32x4*>(src + (rowp + 1) * OP));
                     }
-                    if (PREC == PREC_F16 && p.y_packed == 2) {
-                        const f32x4 qv = v * sy;
-                        const f16x2_t a = __builtin_convertvector(f32x2_t{qv[0], qv[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{qv[2], qv[3]}, f16x2_t);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)op * p.Cout + n0 + col * 4) * 2) =
-                            make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                    if (H16 && p.y_packed == 2) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)op * p.Cout + n0 + col * 4) * 2) = pack16x4<PREC>(v, sy);
                     } else if (p.y_packed) {
                         store_x8(p.y, op, p.Cout, n0 + col * 4, v, sy);
                     } else {
@@ -1479,7 +1487,7 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                 DASV_STAMP(63);
                 return;
             }
-            if (PREC == PREC_F16 && p.y_packed == 2) {
+            if (H16 && p.y_packed == 2) {
                 // half-precision rows: 256 bytes per pixel and 128-channel tile, 32 pixels per pass of the workgroup
                 const int col16 = tid & 15;
 #pragma unroll
@@ -1639,11 +1647,8 @@ __global__ void __launch_bounds__(64 * WM * NWN) conv3x3_window_kernel(const Con
                     for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
                 }
                 note4(v);
-                if (PREC == PREC_F16 && p.y_packed == 2) {
-                    const f32x4 q = v * sy;
-                    const f16x2_t a = __builtin_convertvector(f32x2_t{q[0], q[1]}, f16x2_t), b2 = __builtin_convertvector(f32x2_t{q[2], q[3]}, f16x2_t);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)m * p.Cout + n) * 2) =
-                        make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                if (H16 && p.y_packed == 2) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.y) + ((size_t)m * p.Cout + n) * 2) = pack16x4<PREC>(v, sy);
                 } else if (p.y_packed) store_x8(p.y, m, p.Cout, n, v, sy);
                 else *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
                 csum += v;
@@ -1818,9 +1823,9 @@ static int conv3x3_launch(int mode, const float* x, const float* mel, const floa
     if (y_packed && (mask != nullptr || colsum != nullptr)) return DASV_E_SHAPE;
     if ((x_packed || y_packed) && mel != nullptr) return DASV_E_SHAPE;
     if ((x_packed == 1 || y_packed == 1) && mode != 3) return DASV_E_SHAPE;        // packed split8 planes
-    if ((x_packed == 2 || y_packed == 2) && (mode != 2 || W > 80)) return DASV_E_SHAPE;   // fp16 tensors: the fp16-operand window kernel
+    if ((x_packed == 2 || y_packed == 2) && ((mode != 2 && mode != 1) || W > 80)) return DASV_E_SHAPE;   // 16-bit tensors: the fp16 / bf16 window kernels
     if (mode == 3 && (x_rec == nullptr || (y_packed && y_rec == nullptr))) return DASV_E_NULL;   // split8 scales its operands by the records
-    if ((x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
+    if (mode == 2 && (x_packed == 2 || y_packed == 2) && (x_rec == nullptr || (y_packed == 2 && y_rec == nullptr))) return DASV_E_NULL;
     p.row_span = row_span;
     p.pool = 0; p.pool_units = 0; p.pool_U = 0; p.pool_idx = pool_idx;
     if (pool_idx != nullptr && !pool) return DASV_E_SHAPE;
@@ -1986,6 +1991,14 @@ int dasv_conv3x3_bias_relu_x8_nhwc(const void* x, int x_packed, const uint32_t* 
     return conv3x3_launch(3, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_f16, w_e4m3, bias, nullptr, nullptr,
                           static_cast<float*>(y), workspace, workspace_bytes, B, H, W, Cin, Cout, relu, stream, nullptr,
                           x_packed ? 1 : 0, y_packed ? 1 : 0, x_range, y_range);
+}
+
+int dasv_conv3x3_bias_relu_bf16_nhwc(const void* x, int x_bf16, const void* w_bf16, const float* bias, void* y, int y_bf16, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream) {
+    if (W > 80) return DASV_E_SHAPE;
+    return conv3x3_launch(1, static_cast<const float*>(x), nullptr, nullptr, nullptr, w_bf16, nullptr, bias, nullptr, nullptr,
+                          static_cast<float*>(y), y_bf16 ? nullptr : workspace, y_bf16 ? 0 : workspace_bytes, B, H, W, Cin, Cout, relu, stream,
+                          nullptr, x_bf16 ? 2 : 0, y_bf16 ? 2 : 0, nullptr, nullptr);
 }
 
 int dasv_conv3x3_pool_supported(int mode, int B, int H, int W, int Cin, int Cout) {

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
         if (bias != nullptr) bv[c] = bias[q * 4 + c];
     }
     float sy = 1.f;
-    if (pack) {
+    if (pack == 1 || pack == 2) {
         __shared__ float c1_red[4];
         const float ax = __uint_as_float(x_rec[0] & 0x7fffffffu);
         float bnd = 0.f;
@@ -121,6 +121,12 @@ __global__ void __launch_bounds__(256) conv3x3_c1_kernel(const float* __restrict
                     const h2 a = __builtin_convertvector(f2{o[0] * sy, o[1] * sy}, h2), b2 = __builtin_convertvector(f2{o[2] * sy, o[3] * sy}, h2);
                     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y) + ((size_t)pix * Cout + q * 4) * 2) =
                         make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
+                } else if (pack == 3) {       // bf16 storage chain (bf16-operand mode): round to nearest even, no scale
+                    typedef __bf16 b2t __attribute__((ext_vector_type(2)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const b2t a = __builtin_convertvector(f2{o[0], o[1]}, b2t), b2 = __builtin_convertvector(f2{o[2], o[3]}, b2t);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y) + ((size_t)pix * Cout + q * 4) * 2) =
+                        make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b2));
                 } else if (pack) store_x8(y, pix, Cout, q * 4, o, sy);
                 else *reinterpret_cast<f4*>(y + (size_t)pix * Cout + q * 4) = o;
             }
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
     // fp32 out, unscaled.
     const int cq = C >> 2;
     float sy = 1.f;
-    if (x_rec != nullptr) {
+    if (x_rec != nullptr && in_f16 != 2) {
         const uint32_t xa = x_rec[0];
         int Ey = x8_exp_for(xa);
         if (in_f16) Ey = (int)x_rec[1];
@@ -178,6 +184,32 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
         const int w0 = 2 * wo;
         bool hh = h0 + 1 < H;
         if (pool_src != nullptr) { h0 = pool_src[2 * ho]; hh = pool_src[2 * ho + 1] != 0; }
+        if (in_f16 == 2) {
+            // bf16 tensors (the bf16 storage chain): the values ARE the top halves of floats — widen, compare, narrow (exact)
+            const char* hb = reinterpret_cast<const char*>(x) + ((((size_t)b * H + h0) * W + w0) * C + q * 4) * 2;
+            auto ld = [&](size_t off) {
+                const uint2 u = *reinterpret_cast<const uint2*>(hb + off * 2);
+                return f4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            };
+            auto mxh = [](f4 a, f4 v) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = (v[c] > a[c] || v[c] != v[c]) ? v[c] : a[c];
+                return a;
+            };
+            f4 m = ld(0);
+            const bool hw2 = w0 + 1 < W;
+            if (hw2) m = mxh(m, ld(C));
+            if (hh) m = mxh(m, ld((size_t)W * C));
+            if (hw2 && hh) m = mxh(m, ld((size_t)W * C + C));
+            if (pack == 3) {
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(y) + ((size_t)op * C + q * 4) * 2) =
+                    make_uint2((__float_as_uint(m[0]) >> 16) | (__float_as_uint(m[1]) & 0xffff0000u),
+                               (__float_as_uint(m[2]) >> 16) | (__float_as_uint(m[3]) & 0xffff0000u));
+            } else {
+                *reinterpret_cast<f4*>(y + (size_t)op * C + q * 4) = m;
+            }
+            continue;
+        }
         if (in_f16) {
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             const char* hb = reinterpret_cast<const char*>(x) + ((((size_t)b * H + h0) * W + w0) * C + q * 4) * 2;
@@ -574,7 +606,7 @@ int dasv_ragged_tables(const int* lengths_dev, const int* lengths_host, int B, i
 static int c1_launch(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cout, int relu,
                      const int* row_span, dasv_stream_t stream, int pack, const uint32_t* x_range, uint32_t* y_range) {
     if (x == nullptr || w == nullptr || y == nullptr) return DASV_E_NULL;
-    if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;   // a packed output is scaled from the input's range
+    if ((pack == 1 || pack == 2) && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;   // a packed output is scaled from the input's range
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 4 != 0 || Cout > 1024 || 256 % (Cout / 4) != 0) return DASV_E_SHAPE;
     if (pack == 1 && Cout % 64 != 0) return DASV_E_SHAPE;
     const long long npix = (long long)B * H * W;
@@ -624,9 +656,10 @@ static int pool_launch(const float* x, float* y, const int* pool_src, int B, int
                        const uint32_t* x_range, uint32_t* y_range, dasv_stream_t stream, int in_f16 = 0, uint8_t* idx = nullptr) {
     if (x == nullptr || y == nullptr) return DASV_E_NULL;
     if (idx != nullptr && in_f16) return DASV_E_DTYPE;
-    if (pack && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;
-    if (in_f16 && (x_range == nullptr || pack == 1)) return in_f16 && x_range == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
-    if (pack == 2 && !in_f16) return DASV_E_SHAPE;
+    if ((pack == 1 || pack == 2) && (x_range == nullptr || y_range == nullptr)) return DASV_E_NULL;
+    if (in_f16 == 1 && (x_range == nullptr || pack == 1)) return x_range == nullptr ? DASV_E_NULL : DASV_E_SHAPE;
+    if (pack == 2 && in_f16 != 1) return DASV_E_SHAPE;
+    if ((pack == 3) != (in_f16 == 2 && pack != 0)) return DASV_E_SHAPE;      // bf16 in -> bf16 (pack 3) or fp32 (pack 0) out
     if (B <= 0 || H <= 0 || Ho <= 0 || W <= 0 || C <= 0 || C % (pack == 1 ? 64 : 4) != 0) return DASV_E_SHAPE;
     const int Wo = (W + 1) / 2;
     const long long nvec = (long long)B * Ho * Wo * (C / 4);
@@ -800,6 +833,18 @@ int dasv_conv3x3_c1_bwd_ragged_nhwc(const float* x, const float* y, const float*
                                     size_t workspace_bytes, const int* row_span, int rows, int W, int Cout, dasv_stream_t stream) {
     if (row_span == nullptr) return DASV_E_NULL;
     return c1_bwd_launch(x, y, gy, gw, gb, workspace, workspace_bytes, 1, rows, W, Cout, stream, row_span);
+}
+
+/* the bf16 STORAGE chain of the bf16-operand mode (BASELINE config 3 names bf16): conv11 and the pool on bf16 NHWC tensors — plain
+ * round-to-nearest-even values, no scale and no range record (bf16 has fp32's exponent range) */
+int dasv_conv3x3_c1_bias_relu_bf16_nhwc(const float* x, const float* w, const float* bias, void* y_bf16, int B, int H, int W, int Cout,
+                                        int relu, dasv_stream_t stream) {
+    return c1_launch(x, w, bias, static_cast<float*>(y_bf16), B, H, W, Cout, relu, nullptr, stream, 3, nullptr, nullptr);
+}
+
+int dasv_maxpool2x2_ceil_bf16_nhwc(const void* x_bf16, void* y, int y_bf16, int B, int H, int W, int C, dasv_stream_t stream) {
+    return pool_launch(static_cast<const float*>(x_bf16), static_cast<float*>(y), nullptr, B, H, (H + 1) / 2, W, C, y_bf16 ? 3 : 0, nullptr,
+                       nullptr, stream, 2);
 }
 
 int dasv_colsum_reduce(const float* partial, int rows, int C, float* out, dasv_stream_t stream) {

@@ -506,6 +506,19 @@ void dasv_debug_conv_patch_tiles(int on);
 #endif /* DASV_DEBUG */
 
 /* ------------------------------------------------------------------------
+ * bf16 STORAGE chain for the bf16-operand mode (mode 1; BASELINE config 3 names bf16): activations between the layers as bf16 NHWC
+ * tensors — plain round-to-nearest-even values: no scale, no range record (bf16 has fp32's exponent range) — written by the producer
+ * and copied into the operand window by the consumer, like the fp16 chain above.  x_bf16 / y_bf16: that tensor is bf16; w_bf16 = the
+ * `hi` plane of dasv_conv3x3_pack_weights.  Split-K (workspace) only with an fp32 y.  The inference chain of `CNNs.VGG*` in
+ * conv_mode "bf16" (`half_activations`): conv11 -> bf16 -> conv12 -> bf16 -> pool -> bf16 -> ... -> last pool -> fp32 map.
+ * ------------------------------------------------------------------------ */
+int dasv_conv3x3_bias_relu_bf16_nhwc(const void* x, int x_bf16, const void* w_bf16, const float* bias, void* y, int y_bf16, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int relu, dasv_stream_t stream);
+int dasv_conv3x3_c1_bias_relu_bf16_nhwc(const float* x, const float* w, const float* bias, void* y_bf16, int B, int H, int W, int Cout,
+                                        int relu, dasv_stream_t stream);
+int dasv_maxpool2x2_ceil_bf16_nhwc(const void* x_bf16, void* y, int y_bf16, int B, int H, int W, int C, dasv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * The optimizer step of the training loop (train.py:224 `optimizer.step()` with train.py:82-84 `optim.Adam(net.parameters(), lr,
  * weight_decay)`) over FLAT fp32 buffers: parameters, gradients and both moments share one layout of 64-element-aligned
  * slots (dist.FlatGradReducer's), so the whole model is one HBM pass.  torch's Adam arithmetic: grad += weight_decay * param;

@@ -590,6 +590,56 @@ def test_fp16_activation_chain_vs_oracle_and_range():
     assert _rel(emb, ref) < 1e-3
 
 
+def test_bf16_activation_chain_layers_and_default_model():
+    """BASELINE config 3 names bf16: with conv_mode "bf16" the inference front-end keeps bf16 tensors between its layers
+    (CNNs._forward_map_bf16: plain round-to-nearest-even values, no scale — dasv_conv3x3_bias_relu_bf16_nhwc,
+    dasv_conv3x3_c1_bias_relu_bf16_nhwc, dasv_maxpool2x2_ceil_bf16_nhwc).  Layer by layer: conv11's bf16 output IS the fp32 kernel's
+    output rounded; the pool of a bf16 tensor is exact; a convolution on a bf16 input with a bf16 output is the fp32-output launch on
+    the same input, rounded (same operands: a bf16 input is copied, an fp32 one rounded to the same bits).  Default model at B = 16:
+    embeddings against the same mode with fp32 storage and against oracle.embedding_forward (bf16 arithmetic: 8-bit operands — the
+    bar is this mode's own, 2e-2 relative and cosine within 1e-3; it is never the headline)."""
+    from doubleattentionspeakerverification_amd import conv
+    from doubleattentionspeakerverification_amd.model import SpeakerClassifier
+    x = torch.from_numpy(rnd(51, 3, 21, 80)).to(DEV)
+    w1 = torch.from_numpy(rnd(52, 128, 1, 3, 3, scale=0.3)).to(DEV)
+    b1 = torch.from_numpy(rnd(53, 128, scale=0.1)).to(DEV)
+    h16 = conv.conv3x3_c1_bias_relu_bf16(x, w1, b1)
+    h32 = conv.conv3x3_c1_bias_relu(x, w1, b1)
+    assert h16.dtype == torch.bfloat16 and torch.equal(h16, h32.to(torch.bfloat16))
+    p16 = conv.maxpool2x2_ceil_bf16(h16)
+    assert torch.equal(p16.float(), torch.nn.functional.max_pool2d(h16.float(), 2, stride=2, ceil_mode=True))
+    assert torch.equal(conv.maxpool2x2_ceil_bf16(h16, y_bf16=False), p16.float())
+    w2 = torch.from_numpy(rnd(54, 128, 128, 3, 3, scale=(2.0 / (9 * 128)) ** 0.5)).to(DEV)
+    b2 = torch.from_numpy(rnd(55, 128, scale=0.1)).to(DEV)
+    y16 = conv.conv3x3_bf16(h16, w2, b2, x_bf16=True, y_bf16=True)
+    y32 = conv.conv3x3_bf16(h16, w2, b2, x_bf16=True, y_bf16=False)
+    yf = conv.conv3x3_bf16(h16.float().contiguous(memory_format=torch.channels_last), w2, b2)      # fp32 storage of the same values
+    ref = _conv64(h16.float(), w2.to(torch.bfloat16).float(), b2, relu=True)
+    # bf16 x bf16 products are exact in fp32: only the summation order differs (the fp32-output launches of this small map divide their
+    # channel slabs over workgroups, the bf16-output one does not) — and then one rounding to bf16
+    assert _rel(y32.cpu(), ref) < 1e-5 and _rel(yf.cpu(), ref) < 1e-5
+    assert float((y16.float().cpu() - ref.float()).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+    assert float((y16.float() != y32.to(torch.bfloat16).float()).float().mean()) < 1e-3      # the same values up to ties of the rounding
+    torch.manual_seed(1234)
+    net = SpeakerClassifier(_default_params(), torch.device(DEV)).to(DEV).eval()
+    net.front_end.conv_mode = "bf16"
+    xb = torch.from_numpy(rnd(41, 16, 300, 80))
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    torch.set_num_threads(8)
+    took = []
+    inner = net.front_end._forward_map_bf16
+    net.front_end._forward_map_bf16 = lambda *a: (took.append(1), inner(*a))[1]
+    with torch.no_grad():
+        emb = net.getEmbedding(xb.to(DEV)).cpu()
+        net.front_end.half_activations = False
+        emb32 = net.getEmbedding(xb.to(DEV)).cpu()
+        ref = oracle.embedding_forward(xb, sd, 4, 32)
+    cos = float(torch.nn.functional.cosine_similarity(emb, ref, dim=-1).min())
+    print("bf16 operands + bf16 activation storage: embedding rel err %.2e (fp32 storage: %.2e; between them %.2e), min cosine %.6f"
+          % (_rel(emb, ref), _rel(emb32, ref), _rel(emb, emb32), cos))
+    assert len(took) == 1 and _rel(emb, ref) < 2e-2 and _rel(emb, emb32) < 2e-2 and 1 - cos < 1e-3
+
+
 def test_ragged_fp16_activation_chain_vs_oracle():
     """BASELINE config 5 ("variable-length batches ... fp16 MFMA path"): a ragged group in conv_mode "fp16" keeps fp16 activation
     tensors between its layers (ragged._front_end_ragged_f16, the ragged `_f16` entry points).  Frame vectors against the same mode
