@@ -793,7 +793,7 @@ def main():
             import oracle
             nref = 4
             companions, embs = {}, {}
-            for mode in ("split8", "split", "fp16"):     # timings first (the CPU oracle below lets the GPU clock down)
+            for mode in ("split8", "split", "fp16", "bf16"):     # timings first (the CPU oracle below lets the GPU clock down)
                 net.front_end.conv_mode = mode
                 if mode == args.conv:                    # the headline's own mode: the timed region above IS its measurement
                     embs[mode] = step(0).float()[:nref]
