@@ -232,7 +232,8 @@ class FlatAdam:
     views of the flat parameter buffer (same values, same shapes: state_dict / checkpoints are unaffected).  Parameters that received no
     gradient are skipped — no update, no weight decay — like `grad is None` in the reference (model.py:46,50: b1.*, b3.*).
     `param_groups[0]` carries lr / weight_decay / betas / eps and is read at every step (a scheduler or train.py's manual decay may
-    rewrite it).  GPU only; torch's arithmetic."""
+    rewrite it).  `state_dict()` (what utils.chkptsave stores under 'optimizer', utils.py:23-40) is this class's own layout: the step
+    count and the two flat moment buffers.  GPU only; torch's arithmetic."""
 
     def __init__(self, reducer, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.reducer = reducer
@@ -288,6 +289,9 @@ class FlatAdam:
                 "param_groups": [dict(g) for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        if not sd.get("flat_adam"):
+            raise ValueError("FlatAdam.load_state_dict: not a FlatAdam state (a torch.optim.Adam checkpoint keeps per-parameter moments; "
+                             "construct the trainer with flat_adam=False to resume from it)")
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
