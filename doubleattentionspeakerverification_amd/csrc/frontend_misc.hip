@@ -448,49 +448,60 @@ __global__ void __launch_bounds__(256) conv3x3_c1_bwd_kernel(const float* __rest
     }
 }
 
-// One workgroup per four consecutive (n, t) values: thread j sums partial rows j, j + 256, ... (independent 16-byte loads), then a tree
-// over the 256 partial sums — fixed order.  (Round 3's form, 16 lanes per value, was latency-bound once the partial rows came from
-// conv12's 6,080 patch tiles: ~380 dependent round trips per lane.)
+// One workgroup per SIXTEEN consecutive (n, t) values — one 64-byte line of every partial row: thread (r, q) sums quad q of rows r, r + 64,
+// ... (independent 16-byte loads), then a tree over the 64 row lanes — fixed order.  (Round 3's form, 16 lanes per value, was latency-bound
+// once the partial rows came from conv12's 6,080 patch tiles: ~380 dependent round trips per lane; four values per workgroup used a
+// quarter of every line it touched.)
 __global__ void __launch_bounds__(256) conv3x3_c1_bwd_reduce(const float* __restrict__ part, float* __restrict__ gw,
                                                              float* __restrict__ gb, int nblk, int Cout) {
     __shared__ f4 red[256];
-    const int i0 = blockIdx.x * 4, tid = threadIdx.x;           // values i0 .. i0 + 3 of the [Cout][10] row
+    const int tid = threadIdx.x, q = tid & 3, r = tid >> 2;
+    const int i0 = blockIdx.x * 16 + q * 4;                     // values i0 .. i0 + 3 of the [Cout][10] row
+    const int nval = Cout * 10;
     f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i0 < nval) {
 #pragma unroll 4
-    for (int k = tid; k < nblk; k += 256) v += *reinterpret_cast<const f4*>(part + (size_t)k * Cout * 10 + i0);
+        for (int k = r; k < nblk; k += 64) v += *reinterpret_cast<const f4*>(part + (size_t)k * nval + i0);
+    }
     red[tid] = v;
     __syncthreads();
 #pragma unroll
-    for (int sft = 128; sft >= 1; sft >>= 1) {
+    for (int sft = 128; sft >= 4; sft >>= 1) {                  // over the row lanes (tid >> 2); the quad index stays
         if (tid < sft) red[tid] += red[tid + sft];
         __syncthreads();
     }
-    if (tid < 4) {
-        const int i = i0 + tid, n = i / 10, t = i - n * 10;
-        const float r = red[0][tid];
-        if (t < 9) gw[n * 9 + t] = r;
-        else if (gb != nullptr) gb[n] = r;
+    if (tid < 4 && i0 < nval) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + c, n = i / 10, t = i - n * 10;
+            const float rv = red[tid][c];
+            if (t < 9) gw[n * 9 + t] = rv;
+            else if (gb != nullptr) gb[n] = rv;
+        }
     }
 }
 
 // out[c] = sum_k part[k][c], fixed order — the per-workgroup column sums the pool's backward and the masked data-gradient launches leave
-// behind (bias gradients), a few thousand rows.  One workgroup per four columns: thread t adds rows t, t + 256, ... (independent 16-byte
-// loads, a handful of round trips), then a tree over the 256 partial sums.  (16 lanes per column looping over ~500 rows each was
-// latency-bound: 0.2-0.5 ms per call.)
+// behind (bias gradients), a few thousand rows.  One workgroup per sixteen columns: thread (r, q) adds quad q of rows r, r + 64, ...
+// (independent 16-byte loads), then a tree over the 64 row lanes.  (16 lanes per column looping over ~500 rows each was latency-bound:
+// 0.2-0.5 ms per call.)
 __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int rows, int C) {
     __shared__ f4 red[256];
-    const int c0 = blockIdx.x * 4, tid = threadIdx.x;
+    const int tid = threadIdx.x, q = tid & 3, r = tid >> 2;     // sixteen columns (one 64-byte line of every row) per workgroup
+    const int c0 = blockIdx.x * 16 + q * 4;
     f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
 #pragma unroll 4
-    for (int k = tid; k < rows; k += 256) v += *reinterpret_cast<const f4*>(part + (size_t)k * C + c0);
+        for (int k = r; k < rows; k += 64) v += *reinterpret_cast<const f4*>(part + (size_t)k * C + c0);
+    }
     red[tid] = v;
     __syncthreads();
 #pragma unroll
-    for (int sft = 128; sft >= 1; sft >>= 1) {
+    for (int sft = 128; sft >= 4; sft >>= 1) {                  // over the 64 row lanes; the quad index stays
         if (tid < sft) red[tid] += red[tid + sft];
         __syncthreads();
     }
-    if (tid == 0) *reinterpret_cast<f4*>(out + c0) = red[0];
+    if (tid < 4 && c0 < C) *reinterpret_cast<f4*>(out + c0) = red[tid];
 }
 
 // Border tables of a ragged batch (ragged.py), made on the device from the utterance lengths alone: blockIdx.y = table
@@ -720,13 +731,15 @@ int dasv_maxpool2x2_ceil_ragged_x8_nhwc(const float* x, const uint32_t* x_range,
 static long long maxpool_bwd_blocks(int B, int H, int W, int C) {
     const long long nvec = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     const long long blocks = (nvec + 255) / 256;
-    return blocks > 256 * 32 ? 256 * 32 : blocks;
+    // (2,048 workgroups of grid-stride loops stream as fast as 8,192 and leave a quarter of the column-sum partial rows behind: the
+    // reduction of a block's partials took 16 us for up to 25 MB of them)
+    return blocks > 256 * 8 ? 256 * 8 : blocks;
 }
 
 static long long maxpool_bwd_blocks_out(long long out_rows, int W, int C) {
     const long long nvec = out_rows * ((W + 1) / 2) * (C / 4);
     const long long blocks = (nvec + 255) / 256;
-    return blocks > 256 * 32 ? 256 * 32 : blocks;
+    return blocks > 256 * 8 ? 256 * 8 : blocks;
 }
 
 static int maxpool_bwd_launch(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int relu_mask,
@@ -850,7 +863,7 @@ int dasv_maxpool2x2_ceil_bf16_nhwc(const void* x_bf16, void* y, int y_bf16, int 
 int dasv_colsum_reduce(const float* partial, int rows, int C, float* out, dasv_stream_t stream) {
     if (partial == nullptr || out == nullptr) return DASV_E_NULL;
     if (rows <= 0 || C <= 0 || C % 4 != 0) return DASV_E_SHAPE;
-    hipLaunchKernelGGL(dasv::colsum_reduce_kernel, dim3((unsigned)(C / 4)), dim3(256), 0, (hipStream_t)stream, partial, out, rows, C);
+    hipLaunchKernelGGL(dasv::colsum_reduce_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, (hipStream_t)stream, partial, out, rows, C);
     return (int)hipGetLastError();
 }
 
@@ -858,7 +871,7 @@ int dasv_conv3x3_c1_bwd_reduce_parts(const float* partial, int rows, float* gw, 
     if (partial == nullptr || gw == nullptr) return DASV_E_NULL;
     if (rows <= 0 || Cout <= 0) return DASV_E_SHAPE;
     if (Cout % 2 != 0) return DASV_E_SHAPE;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)(Cout * 10 / 4)), dim3(256), 0, (hipStream_t)stream, partial, gw, gb, rows, Cout);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 + 15) / 16)), dim3(256), 0, (hipStream_t)stream, partial, gw, gb, rows, Cout);
     return (int)hipGetLastError();
 }
 
@@ -880,7 +893,7 @@ static int c1_bwd_launch(const float* x, const float* y, const float* gy, float*
                        pix_per_block, row_span);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)(Cout * 10 / 4)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
+    hipLaunchKernelGGL(dasv::conv3x3_c1_bwd_reduce, dim3((unsigned)((Cout * 10 + 15) / 16)), dim3(256), 0, s, part, gw, gb, nblk, Cout);
     return (int)hipGetLastError();
 }
 
