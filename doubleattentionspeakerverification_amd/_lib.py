@@ -34,6 +34,7 @@ SIGNATURES = {
     "dasv_conv3x3_packed_weight_bytes_x8": (c_size_t, [c_int, c_int]),
     "dasv_conv3x3_pack_weights_x8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_pack_weights_x8_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dasv_conv3x3_pack_weights_x8_dgrad_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_range_absmax_f32": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "dasv_conv3x3_pack_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dasv_conv3x3_packed_weight_bytes_f16": (c_size_t, [c_int, c_int]),

@@ -172,9 +172,12 @@ def _pack_dgrad_x8(weight):
     n = max(lib.dasv_conv3x3_packed_weight_bytes(cin, cout), lib.dasv_conv3x3_packed_weight_bytes_f16(cin, cout))
     hi = torch.empty(n, dtype=torch.uint8, device=weight.device)
     lo = torch.empty(max(n, lib.dasv_conv3x3_packed_weight_bytes_x8(cin, cout)), dtype=torch.uint8, device=weight.device)
+    # small layers: index arithmetic on the forward weight (one launch); large ones: a tiled transpose-and-flip through scratch, then the
+    # row-wise pack (measured on conv42: 215 us direct, 116 us with torch's flip + copy + pack, ~65 us this way)
+    scratch = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device) if cin * cout > 256 * 256 else None
     with torch.cuda.device(weight.device):
-        rc = lib.dasv_conv3x3_pack_weights_x8_dgrad(weight.data_ptr(), hi.data_ptr(), lo.data_ptr(), cout, cin,
-                                                    torch.cuda.current_stream(weight.device).cuda_stream)
+        rc = lib.dasv_conv3x3_pack_weights_x8_dgrad_ws(weight.data_ptr(), None if scratch is None else scratch.data_ptr(), hi.data_ptr(),
+                                                       lo.data_ptr(), cout, cin, torch.cuda.current_stream(weight.device).cuda_stream)
     _lib.check(rc, "dasv_conv3x3_pack_weights_x8_dgrad")
     return hi, lo
 
@@ -434,10 +437,8 @@ def _conv_backward(ctx, x, weight, g, g_rec_in, cout_p, g_packed=False):
         # (the kernel writes 128-channel tiles: an input with a 64-multiple of channels gets its gradient through a padded
         # transposed layer and a slice — narrow kernel sizes only)
         n_out = (cin_x + 127) // 128 * 128
-        if (dmode == "split8" and not padded and n_out == cin_x and weight.dtype == torch.float32 and weight.is_contiguous()
-                and cin * cout <= 256 * 256):
-            # straight from the layer's weight, no transposed copy: one launch instead of four for the small layers (measured:
-            # 8-22 us against 25-35); its strided reads lose on the large ones (conv42: 215 us against 116 for flip + copy + pack)
+        if dmode == "split8" and not padded and n_out == cin_x and weight.dtype == torch.float32 and weight.is_contiguous():
+            # straight from the layer's weight (conv._pack_dgrad_x8): no torch flip / copy / temporaries
             hi, lo = _pack_dgrad_x8(weight.detach())
         else:
             wt = weight.detach()

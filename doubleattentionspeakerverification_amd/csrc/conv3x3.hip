@@ -142,8 +142,9 @@ __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const floa
     const int o = blockIdx.x, tid = threadIdx.x, n = 9 * Cin;
     // transposed: w is the weight [Cin][Cout][3][3] of the layer whose DATA GRADIENT these planes compute — the same convolution with
     // the weights transposed over (out, in) and flipped over (ky, kx): plane element (o, tap, c) = w[c][o][8 - tap]
+    // (transposed == 2: w is already the transposed, flipped tensor — read like a forward weight, treated like data-gradient planes)
     auto src = [&](int c, int tap) -> float {
-        return transposed ? w[((size_t)c * Cout + o) * 9 + (8 - tap)] : w[((size_t)o * Cin + c) * 9 + tap];
+        return transposed == 1 ? w[((size_t)c * Cout + o) * 9 + (8 - tap)] : w[((size_t)o * Cin + c) * 9 + tap];
     };
     uint8_t* aux = w8 + (size_t)Cout * n * 2;
     float* winv = reinterpret_cast<float*>(aux + (size_t)Cout * 4);
@@ -221,6 +222,23 @@ __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const floa
         uint8_t* row = w8 + (((size_t)o * 9 + tap) * nslab + c / 64) * 128;
         *reinterpret_cast<uint32_t*>(row + c % 64) = (uint32_t)r8;
         *reinterpret_cast<uint32_t*>(row + 64 + c % 64) = (uint32_t)v8;
+    }
+}
+
+// wt[c][o][8 - tap] = w[o][c][tap]: the weight of a layer's DATA-GRADIENT convolution (transposed over (out, in), flipped over (ky, kx)) as
+// an fp32 tensor in torch layout [Cin][Cout][3][3], through a 32 x 32 x 9 LDS tile so that both the reads (288 consecutive floats of one
+// output channel) and the writes (288 consecutive floats of one input channel) are contiguous.  One launch instead of torch's flip + copy.
+__global__ void __launch_bounds__(256) conv3x3_transpose_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin) {
+    __shared__ float tile[32][32 * 9 + 1];
+    const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+    for (int i = tid; i < 32 * 288; i += 256) {
+        const int ol = i / 288, r = i - ol * 288;                 // r = cl * 9 + tap
+        tile[ol][r] = (o0 + ol < Cout && c0 + r / 9 < Cin) ? w[((size_t)(o0 + ol) * Cin + c0) * 9 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 288; i += 256) {
+        const int cl = i / 288, r = i - cl * 288, ol = r / 9, tp = r - ol * 9;
+        if (c0 + cl < Cin && o0 + ol < Cout) wt[((size_t)(c0 + cl) * Cout + o0 + ol) * 9 + tp] = tile[ol][cl * 9 + 8 - tp];
     }
 }
 
@@ -1767,8 +1785,22 @@ int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16,
 }
 
 int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
+    return dasv_conv3x3_pack_weights_x8_dgrad_ws(w, nullptr, w_f16, w_e4m3, Cout, Cin, stream);
+}
+
+int dasv_conv3x3_pack_weights_x8_dgrad_ws(const float* w, float* scratch, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
     if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0 || Cout % 64 != 0) return DASV_E_SHAPE;
+    if (scratch != nullptr) {
+        // large layers: the transposed, flipped weight goes through `scratch` ([Cin][Cout][3][3] floats) with contiguous reads and writes,
+        // then the row-wise pack reads it like a forward weight (mode 2: no output bounds) — the index arithmetic of the direct form reads
+        // 36-byte pieces a whole row apart, which loses above ~256 x 256 channels
+        hipLaunchKernelGGL(dasv::conv3x3_transpose_flip_kernel, dim3((unsigned)((Cout + 31) / 32), (unsigned)((Cin + 31) / 32)), dim3(256), 0,
+                           (hipStream_t)stream, w, scratch, Cout, Cin);
+        hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, scratch, nullptr,
+                           static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 2);
+        return (int)hipGetLastError();
+    }
     // planes of the convolution with Cin outputs and Cout inputs
     hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, w, nullptr,
                        static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 1);

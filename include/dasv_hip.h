@@ -170,6 +170,9 @@ size_t dasv_conv3x3_packed_weight_bytes_x8(int Cout, int Cin);
 int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16, void* w_e4m3, int Cout, int Cin,
                                  dasv_stream_t stream);
 int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
+/* the same planes through `scratch` (Cout * Cin * 9 floats; NULL = the call above): a tiled transpose-and-flip into scratch, then the
+ * row-wise pack — contiguous reads and writes throughout, the form for large layers (512 x 512 channels and up) */
+int dasv_conv3x3_pack_weights_x8_dgrad_ws(const float* w, float* scratch, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
 
 /* RANGE RECORDS.  A range record is uint32_t[2] in device memory beside an activation tensor: [0] = the bit pattern of
  * max |v| over the tensor (kept by the kernel that writes the tensor with an atomic maximum; the caller zeroes the record

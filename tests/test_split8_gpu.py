@@ -346,12 +346,13 @@ def test_packed_training_chain_gradients_vs_float64_under_the_same_decisions(fir
     assert _rel(y2.detach(), y.detach()) < 2e-5
 
 
-@pytest.mark.parametrize("cout,cin", [(128, 64), (64, 128), (256, 128), (128, 384)])
+@pytest.mark.parametrize("cout,cin", [(128, 64), (64, 128), (256, 128), (128, 384), (512, 512), (1024, 512)])
 def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin):
     """dasv_conv3x3_pack_weights_x8_dgrad: the split8 planes of a layer's data-gradient convolution (train.py:220; the weights
     transposed over (out, in) and flipped over (ky, kx)) packed straight from the layer's weight must be the planes
     dasv_conv3x3_pack_weights_x8 makes from an explicitly transposed and flipped copy — byte for byte (fp16 plane, e4m3 planes, scale
-    bytes, channel scales)."""
+    bytes, channel scales).  Small layers by index arithmetic on the forward weight, large ones (the last two shapes) through a tiled
+    transpose-and-flip into scratch (dasv_conv3x3_pack_weights_x8_dgrad_ws)."""
     from doubleattentionspeakerverification_amd import conv
     w = torch.from_numpy(rnd(17, cout, cin, 3, 3, scale=0.05)).to(DEV)
     w[3, 5] *= 1e4                                      # channels of very different magnitude: per-channel scales
