@@ -55,7 +55,7 @@ def main():
     dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     esize = 4 if dt == torch.float32 else 2
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.debug_probe()       # the developer build (libdasv_hip_dbg.so): the same kernels plus dasv_debug_set_tuning
     nbuf = args.nbuf if args.nbuf > 0 else max(8, int(np.ceil(300e6 / (B * T * D * esize))))
     g = torch.Generator(device=dev).manual_seed(1234)
     xs = [torch.randn(B, T, D, device=dev, generator=g).to(dt) for _ in range(nbuf)]
