@@ -10,6 +10,7 @@ Activations stay fp32 in NHWC memory (torch `channels_last` tensors are passed z
             bf16 operands, whose exponent range covers small gradients).  Backward: data gradient = the same kernel with transposed, flipped weights; weight gradient =
 csrc/conv3x3_wgrad.hip.
 """
+import threading
 import weakref
 
 import torch
@@ -51,6 +52,7 @@ def exact(cin, cout):
 
 
 _REC_POOLS = {}      # (device, stream) -> [zeroed int32 [1024, 2] block, rows handed out]
+_REC_LOCK = threading.Lock()      # (two host threads driving the same stream must never be handed the same row)
 
 
 def new_ranges(device, n=1):
@@ -64,11 +66,14 @@ def new_ranges(device, n=1):
     if device.type != "cuda" or n > 256 or torch.cuda.is_current_stream_capturing():
         return torch.zeros((n, 2), dtype=torch.int32, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    pool = _REC_POOLS.get(key)
-    if pool is None or pool[1] + n > pool[0].shape[0]:
-        pool = _REC_POOLS[key] = [torch.zeros((1024, 2), dtype=torch.int32, device=device), 0]
-    r = pool[0][pool[1]:pool[1] + n]
-    pool[1] += n
+    with _REC_LOCK:
+        pool = _REC_POOLS.get(key)
+        if pool is None or pool[1] + n > pool[0].shape[0]:
+            if len(_REC_POOLS) > 64:         # streams come and go: drop the blocks of old ones (rows in use keep their block alive)
+                _REC_POOLS.clear()
+            pool = _REC_POOLS[key] = [torch.zeros((1024, 2), dtype=torch.int32, device=device), 0]
+        r = pool[0][pool[1]:pool[1] + n]
+        pool[1] += n
     return r
 
 
