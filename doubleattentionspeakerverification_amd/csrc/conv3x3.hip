@@ -128,6 +128,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // (the E8M0 block scales of the MFMA) | [Cout] floats 2^-Ew[n] | { max_n sum_k |w[n][k]|, max_n |bias[n]|, 0, 0 } — the last two bound
 // the layer's output from its input's maximum (|y| <= amax_x * L1 + |b|), which is what a PACKED output is scaled by before any of
 // it exists.  One workgroup per output channel.
+// dynamic LDS of the pack kernel: one channel's 9 * Cin floats when that fits the 64 KB a launch may ask for without opting in
+static inline size_t pack_row_lds(int Cin) { return (size_t)Cin * 36 <= 65536 - 64 ? (size_t)Cin * 36 : 0; }
 __device__ __forceinline__ float block_max256(float v, float* red) {
     v = group_max<64>(v);
     __syncthreads();
@@ -137,15 +139,28 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
 }
 __global__ void __launch_bounds__(256) conv3x3_pack_weights_x8_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                                        uint16_t* __restrict__ wh, uint8_t* __restrict__ w8, int Cout, int Cin,
-                                                                       int transposed) {
+                                                                       int transposed, int staged) {
     __shared__ float red[4];
+    extern __shared__ float wrow[];          // staged != 0: the channel's 9 * Cin source values, in (c, tap) order
     const int o = blockIdx.x, tid = threadIdx.x, n = 9 * Cin;
     // transposed: w is the weight [Cin][Cout][3][3] of the layer whose DATA GRADIENT these planes compute — the same convolution with
     // the weights transposed over (out, in) and flipped over (ky, kx): plane element (o, tap, c) = w[c][o][8 - tap]
     // (transposed == 2: w is already the transposed, flipped tensor — read like a forward weight, treated like data-gradient planes)
-    auto src = [&](int c, int tap) -> float {
+    auto gsrc = [&](int c, int tap) -> float {
         return transposed == 1 ? w[((size_t)c * Cout + o) * 9 + (8 - tap)] : w[((size_t)o * Cin + c) * 9 + tap];
     };
+    // the three passes below each wait out the memory latency of their own loads when they read `w` (a workgroup has ~18 dependent
+    // trips per pass and the grid is two workgroups per CU): with the row staged in LDS first — all of its loads in flight at once —
+    // they read LDS instead.  Same values in the same order: the planes are bitwise those of the unstaged form.
+    if (staged) {
+        if (transposed != 1)
+            for (int i = tid * 4; i < n; i += 1024)
+                *reinterpret_cast<float4*>(wrow + i) = *reinterpret_cast<const float4*>(w + (size_t)o * n + i);
+        else
+            for (int i = tid; i < n; i += 256) wrow[i] = gsrc(i / 9, i % 9);
+        __syncthreads();
+    }
+    auto src = [&](int c, int tap) -> float { return staged ? wrow[c * 9 + tap] : gsrc(c, tap); };
     uint8_t* aux = w8 + (size_t)Cout * n * 2;
     float* winv = reinterpret_cast<float*>(aux + (size_t)Cout * 4);
     uint32_t* tail = reinterpret_cast<uint32_t*>(aux + (size_t)Cout * 8);   // zeroed by the host wrapper before this launch
@@ -1779,8 +1794,9 @@ int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16,
     if (Cout <= 0 || Cin <= 0 || Cin % 64 != 0) return DASV_E_SHAPE;
     hipError_t e = hipMemsetAsync(static_cast<char*>(w_e4m3) + (size_t)Cout * 9 * Cin * 2 + (size_t)Cout * 8, 0, 16, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, w, bias,
-                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin, 0);
+    const size_t row = dasv::pack_row_lds(Cin);
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cout), dim3(256), row, (hipStream_t)stream, w, bias,
+                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cout, Cin, 0, row != 0 ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -1791,19 +1807,20 @@ int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3
 int dasv_conv3x3_pack_weights_x8_dgrad_ws(const float* w, float* scratch, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream) {
     if (w == nullptr || w_f16 == nullptr || w_e4m3 == nullptr) return DASV_E_NULL;
     if (Cout <= 0 || Cin <= 0 || Cout % 64 != 0) return DASV_E_SHAPE;
+    const size_t row = dasv::pack_row_lds(Cout);       // (the planes' input channels are this layer's output channels)
     if (scratch != nullptr) {
         // large layers: the transposed, flipped weight goes through `scratch` ([Cin][Cout][3][3] floats) with contiguous reads and writes,
         // then the row-wise pack reads it like a forward weight (mode 2: no output bounds) — the index arithmetic of the direct form reads
         // 36-byte pieces a whole row apart, which loses above ~256 x 256 channels
         hipLaunchKernelGGL(dasv::conv3x3_transpose_flip_kernel, dim3((unsigned)((Cout + 31) / 32), (unsigned)((Cin + 31) / 32)), dim3(256), 0,
                            (hipStream_t)stream, w, scratch, Cout, Cin);
-        hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, scratch, nullptr,
-                           static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 2);
+        hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), row, (hipStream_t)stream, scratch, nullptr,
+                           static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 2, row != 0 ? 1 : 0);
         return (int)hipGetLastError();
     }
     // planes of the convolution with Cin outputs and Cout inputs
-    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), 0, (hipStream_t)stream, w, nullptr,
-                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 1);
+    hipLaunchKernelGGL(dasv::conv3x3_pack_weights_x8_kernel, dim3((unsigned)Cin), dim3(256), row, (hipStream_t)stream, w, nullptr,
+                       static_cast<uint16_t*>(w_f16), static_cast<uint8_t*>(w_e4m3), Cin, Cout, 1, row != 0 ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -346,14 +346,21 @@ def test_packed_training_chain_gradients_vs_float64_under_the_same_decisions(fir
     assert _rel(y2.detach(), y.detach()) < 2e-5
 
 
-@pytest.mark.parametrize("cout,cin", [(128, 64), (64, 128), (256, 128), (128, 384), (512, 512), (1024, 512)])
-def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin):
+@pytest.mark.parametrize("cout,cin,route", [(128, 64, "direct"), (64, 128, "direct"), (256, 128, "direct"), (128, 384, "direct"),
+                                            (512, 512, "direct"), (1024, 512, "direct"), (512, 512, "scratch"), (1024, 512, "scratch"),
+                                            (1856, 64, "direct")])
+def test_data_gradient_planes_packed_from_the_forward_weight(cout, cin, route, monkeypatch):
     """dasv_conv3x3_pack_weights_x8_dgrad: the split8 planes of a layer's data-gradient convolution (train.py:220; the weights
     transposed over (out, in) and flipped over (ky, kx)) packed straight from the layer's weight must be the planes
     dasv_conv3x3_pack_weights_x8 makes from an explicitly transposed and flipped copy — byte for byte (fp16 plane, e4m3 planes, scale
-    bytes, channel scales).  Small layers by index arithmetic on the forward weight, large ones (the last two shapes) through a tiled
-    transpose-and-flip into scratch (dasv_conv3x3_pack_weights_x8_dgrad_ws)."""
+    bytes, channel scales).  "direct": index arithmetic on the forward weight, the gathered row staged in LDS (1856 channels: a row
+    too long for LDS, read from memory pass by pass); "scratch": through a tiled transpose-and-flip
+    (dasv_conv3x3_pack_weights_x8_dgrad_ws), the route of large layers whose rows do not fit."""
     from doubleattentionspeakerverification_amd import conv
+    if route == "scratch":
+        monkeypatch.setattr(conv, "_DGRAD_ROW_FITS", 0)
+    else:
+        monkeypatch.setattr(conv, "_DGRAD_SCRATCH_ABOVE", 1 << 40)
     w = torch.from_numpy(rnd(17, cout, cin, 3, 3, scale=0.05)).to(DEV)
     w[3, 5] *= 1e4                                      # channels of very different magnitude: per-channel scales
     w[:, 7] *= 1e-6
