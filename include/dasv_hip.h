@@ -171,7 +171,8 @@ int dasv_conv3x3_pack_weights_x8(const float* w, const float* bias, void* w_f16,
                                  dasv_stream_t stream);
 int dasv_conv3x3_pack_weights_x8_dgrad(const float* w, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
 /* the same planes through `scratch` (Cout * Cin * 9 floats; NULL = the call above): a tiled transpose-and-flip into scratch, then the
- * row-wise pack — contiguous reads and writes throughout, the form for large layers (512 x 512 channels and up) */
+ * row-wise pack — contiguous reads and writes throughout.  The call above stages each gathered row (9 * Cout floats) in LDS and is the
+ * faster one whenever that fits 64 KB (Cout <= 1818); this form is for longer rows */
 int dasv_conv3x3_pack_weights_x8_dgrad_ws(const float* w, float* scratch, void* w_f16, void* w_e4m3, int Cout, int Cin, dasv_stream_t stream);
 
 /* RANGE RECORDS.  A range record is uint32_t[2] in device memory beside an activation tensor: [0] = the bit pattern of
