@@ -152,6 +152,31 @@ __global__ void __launch_bounds__(256) range_absmax_kernel(const float* __restri
     range_note_block(rec, m, &s_amax);
 }
 
+// element i of a pooled map's [windows][C / 4] index space -> channel quad q, window op = (b, ho, wo).  The five 64-bit divisions this
+// used to be cost more VALU time than the window's 16 bytes of traffic (a 64-bit division is ~150 instructions; the kernels ran at
+// 2.0-2.6 TB/s): 32-bit arithmetic whenever the index space fits (always, in practice), a shift for the usual power-of-two C.
+__device__ __forceinline__ void pool_window_of(long long i, int cq, int Wo, int Ho, long long nvec, int& q, long long& op, int& wo, int& ho,
+                                               long long& b) {
+    if (nvec < (1ll << 31)) {
+        const uint32_t ii = (uint32_t)i;
+        uint32_t o;
+        if ((cq & (cq - 1)) == 0) { o = ii >> (31 - __builtin_clz((uint32_t)cq)); q = (int)(ii & (uint32_t)(cq - 1)); }
+        else { o = ii / (uint32_t)cq; q = (int)(ii - o * (uint32_t)cq); }
+        const uint32_t r = o / (uint32_t)Wo;
+        wo = (int)(o - r * (uint32_t)Wo);
+        const uint32_t bb = r / (uint32_t)Ho;
+        ho = (int)(r - bb * (uint32_t)Ho);
+        op = (long long)o;
+        b = (long long)bb;
+        return;
+    }
+    q = (int)(i % cq);
+    op = i / cq;
+    wo = (int)(op % Wo);
+    ho = (int)((op / Wo) % Ho);
+    b = op / ((long long)Wo * Ho);
+}
+
 // x [B,H,W,C] -> y [B,Ho,Wo,C], Ho = ceil(H/2), Wo = ceil(W/2); windows clipped at the bottom/right edge (ceil_mode)
 // ragged batch (pool_src != null): B == 1, Ho = total output rows; pool_src[ro] = {first input row, 1 if the window has a second row}
 // x_rec / y_rec (optional; both required with pack): the pooled map's range record is its input's — every input element lies in a
@@ -176,10 +201,9 @@ __global__ void __launch_bounds__(256) maxpool2x2_nhwc_kernel(const float* __res
         if (y_rec != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { y_rec[0] = xa; y_rec[1] = (uint32_t)Ey; }
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq);
-        const long long op = i / cq;
-        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
-        const long long b = op / ((long long)Wo * Ho);
+        int q, wo, ho;
+        long long op, b;
+        pool_window_of(i, cq, Wo, Ho, nvec, q, op, wo, ho, b);
         int h0 = 2 * ho;
         const int w0 = 2 * wo;
         bool hh = h0 + 1 < H;
@@ -291,10 +315,9 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_nhwc_kernel(const float* _
         if (blockIdx.x == 0 && threadIdx.x == 0) { gx_rec[0] = ga; gx_rec[1] = (uint32_t)Eg; }
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq);
-        const long long op = i / cq;
-        const int wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
-        const long long b = op / ((long long)Wo * Ho);
+        int q, wo, ho;
+        long long op, b;
+        pool_window_of(i, cq, Wo, Ho, nvec, q, op, wo, ho, b);
         int h0 = 2 * ho;
         const int w0 = 2 * wo;
         bool hh = h0 + 1 < H;
