@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#define CK(x) do { if ((x) != hipSuccess) { printf("HIP error at line %d\n", __LINE__); return; } } while (0)
+#define CKM(x) do { if ((x) != hipSuccess) { printf("HIP error at line %d\n", __LINE__); return 1; } } while (0)
 
 constexpr int C = 64, W = 80, H = 300, B = 64;
 constexpr long long NPIX = (long long)B * H * W;
@@ -93,23 +95,23 @@ __global__ void __launch_bounds__(256) k_window_rd(float* y, const float4* __res
 
 template <typename F>
 static void run(const char* name, F launch, float* y, size_t bytes) {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < 3; ++r) launch(y + (r & 1) * (bytes / 4));
-    hipDeviceSynchronize();
+    CK(hipDeviceSynchronize());
     const int reps = 20;
-    hipEventRecord(e0);
+    CK(hipEventRecord(e0));
     for (int r = 0; r < reps; ++r) launch(y + (r & 1) * (bytes / 4));
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-34s %7.1f us  %5.2f TB/s\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
 }
 
 int main() {
     const size_t bytes = (size_t)NPIX * C * 4;
-    float* y; hipMalloc(&y, 2 * bytes); hipMemset(y, 0, 2 * bytes);
+    float* y; CKM(hipMalloc(&y, 2 * bytes)); CKM(hipMemset(y, 0, 2 * bytes));
     float4* g; uint32_t* idx;
-    hipMalloc(&g, bytes / 4); hipMalloc(&idx, bytes / 16);
-    hipMemset(g, 0, bytes / 4); hipMemset(idx, 1, bytes / 16);
+    CKM(hipMalloc(&g, bytes / 4)); CKM(hipMalloc(&idx, bytes / 16));
+    CKM(hipMemset(g, 0, bytes / 4)); CKM(hipMemset(idx, 1, bytes / 16));
     for (int blocks : {2048, 8192, 65536}) {
         printf("grid %d workgroups of 256\n", blocks);
         run("plain 16-byte stores", [&](float* d) { hipLaunchKernelGGL(k_plain16, dim3(blocks), dim3(256), 0, 0, d, NPIX * 16); }, y, bytes);
